@@ -1,0 +1,104 @@
+"""CPU: pin oracle/ref_cpu.py against the fixtures produced from the reference itself
+(tools/gen_golden.py imports /root/reference; fixtures are committed under tests/golden/)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_cpu
+
+CASES = ["unet_c8_f4_2x32x32", "unet_c2_f4_1x48x64_dice", "unet_in3_c3_f4_2x32x48",
+         "unet_c8_f8_1x32x64_light"]
+
+
+def load_case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    w0 = {k[3:]: z[k] for k in z.files if k.startswith("w0/")}
+    return z, w0
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_unet_forward_loss_grads(golden_dir, name):
+    z, w0 = load_case(golden_dir, name)
+    w_ce, w_dice, lr, mom, eps = z["hyper"]
+    net = ref_cpu.OracleUNet(w0)
+    probs, (loss, ce, dice), grads = net.loss_and_grads(z["x"], z["target"], w_ce, w_dice, eps)
+    np.testing.assert_allclose(net.logits, z["logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(probs, z["probs"], rtol=1e-4, atol=1e-6)
+    am = probs.argmax(1)
+    # bit-identical class maps wherever the reference's own top-2 margin exceeds fp32 noise
+    top2 = np.sort(z["probs"], axis=1)[:, -2:]
+    safe = (top2[:, 1] - top2[:, 0]) > 1e-5
+    assert np.array_equal(am[safe], z["argmax"][safe])
+    assert (am != z["argmax"]).sum() <= 2
+    np.testing.assert_allclose([loss, ce, dice], z["loss"], rtol=2e-6, atol=1e-7)
+    n = 0
+    for k in z.files:
+        if k.startswith("g0/"):
+            ref = z[k]
+            tol = 1e-4 * max(1e-3, float(np.abs(ref).max()))
+            np.testing.assert_allclose(grads[k[3:]], ref, rtol=1e-3, atol=tol, err_msg=k)
+            n += 1
+    assert n > 0
+    for k in z.files:
+        if k.startswith("b1/"):
+            np.testing.assert_allclose(net.s[k[3:]], z[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("name", CASES[:2])
+def test_unet_eval_and_sgd_trajectory(golden_dir, name):
+    z, w0 = load_case(golden_dir, name)
+    w_ce, w_dice, lr, mom, eps = z["hyper"]
+    steps = int(z["meta"][6])
+    net = ref_cpu.OracleUNet(w0)
+    losses = []
+    for i in range(steps):
+        _, (loss, _, _), grads = net.loss_and_grads(z["x"], z["target"], w_ce, w_dice, eps)
+        if i == 0:
+            pe = net.forward(z["x"], train=False)
+            np.testing.assert_allclose(pe, z["probs_eval"], rtol=1e-4, atol=1e-6)
+        losses.append(loss)
+        net.sgd_step(grads, lr, mom)
+    np.testing.assert_allclose(losses, z["traj_loss"], rtol=1e-5)
+    for k in z.files:
+        if k.startswith("wN/") and "num_batches" not in k:
+            ref = z[k]
+            np.testing.assert_allclose(net.s[k[3:]], ref, rtol=1e-3,
+                                       atol=1e-4 * max(1e-2, float(np.abs(ref).max())), err_msg=k)
+        elif k.startswith("wN/"):
+            assert int(net.s[k[3:]]) == int(z[k])
+
+
+def test_unet_rejects_non_multiple_of_16(golden_dir):
+    z = np.load(os.path.join(golden_dir, "api.npz"))
+    assert "Sizes of tensors must match" in str(z["negative_msg"])
+    _, w0 = load_case(golden_dir, CASES[1])
+    net = ref_cpu.OracleUNet(w0)
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        net.forward(np.zeros((1, 1, 62, 96)))
+
+
+def test_metrics_known_answers(golden_dir):
+    z = np.load(os.path.join(golden_dir, "metrics.npz"))
+    cases = sorted({k.split("/")[1] for k in z.files if k.startswith("in/")})
+    assert len(cases) >= 8
+    for c in cases:
+        yt, yp = z[f"in/{c}/y_true"], z[f"in/{c}/y_pred"]
+        for fname, fn in ref_cpu.METRIC_FUNCS.items():
+            key = f"out/{c}/{fname}"
+            if key not in z.files:
+                continue
+            got = fn(yt, yp)
+            np.testing.assert_allclose(got, z[key], rtol=1e-6 if yt.dtype == np.float32 else 1e-12,
+                                       atol=0, err_msg=key)
+
+
+def test_metrics_seeded_full_size(golden_dir):
+    z = np.load(os.path.join(golden_dir, "metrics.npz"))
+    rng = np.random.default_rng(1234)
+    a = (rng.random((32, 512, 1024)) < 0.3).astype(np.uint8)
+    b = (rng.random((32, 512, 1024)) < 0.3).astype(np.uint8)
+    c = ref_cpu.confusion_sums(a, b)
+    assert [int(c["tp"]), int(c["t"]), int(c["p"]), c["n"]] == z["seeded_counts"].tolist()
+    for fname, fn in ref_cpu.METRIC_FUNCS.items():
+        np.testing.assert_allclose(fn(a, b), z[f"out/seeded_32x512x1024/{fname}"], rtol=1e-13)
