@@ -1,0 +1,234 @@
+/*
+ * oct_hip.h -- C ABI of liboct_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * U-Net training hot path of ZhangHH233/Retinal_OCT_Image_Segmentation_via_Deep_Learning.
+ *
+ * The reference has no FFI of its own: its boundary is Python, and every op on
+ * the path is a stock torch.nn call.  Each entry point below replaces the torch op(s) at the
+ * cited reference call site; INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless marked host.
+ *   - the library never allocates or frees memory and never synchronises: work is enqueued on the
+ *     hipStream_t passed as `void* stream`; hipSetDevice is the caller's job.
+ *   - every function returns 0 on success or a negative code (OCT_E_*); it never throws/aborts.
+ *     oct_get_last_error() returns the message of the calling thread's last failure.
+ *   - re-entrant: no global mutable state besides the thread-local error string (backward is
+ *     called from PyTorch's autograd thread).
+ *   - activation tensors are NHWC ("channels-last") in the dtype named by `dtype`
+ *     (OCT_DT_BF16 production, OCT_DT_F32 parity mode); accumulation is always fp32.
+ *     Parameters, gradients, BN statistics and losses are fp32.  The network input
+ *     (B,Cin,H,W) and output (B,Ccls,H,W) keep the reference's NCHW layout.
+ */
+#ifndef OCT_HIP_H
+#define OCT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCT_VERSION 100 /* 0.1.0 */
+
+/* dtypes of activation storage */
+#define OCT_DT_BF16 0
+#define OCT_DT_F32 1
+
+/* error codes */
+#define OCT_OK 0
+#define OCT_E_INVALID (-22)  /* bad descriptor / unsupported shape */
+#define OCT_E_LAUNCH (-5)    /* hipLaunch failure */
+#define OCT_E_NODEVICE (-19) /* no HIP device */
+
+/* source transform applied while a conv stages its input (BN-apply + ReLU fused on load) */
+#define OCT_XF_NONE 0
+#define OCT_XF_AFFINE_RELU 1 /* a = max(x*scale[c] + shift[c], 0) */
+
+/* input / output addressing of the implicit GEMM */
+#define OCT_IN_PLAIN 0
+#define OCT_IN_S2D 1  /* input pixel (y,x) gathers the 2x2 block of a 2H x 2W tensor: k=(dy*2+dx)*C+c */
+#define OCT_OUT_PLAIN 0
+#define OCT_OUT_D2S 1 /* GEMM column n=(dy*2+dx)*C+co is stored at pixel (2y+dy, 2x+dx), channel co */
+
+/* weight packing modes (fp32 torch layout -> MFMA A-fragment order in the activation dtype) */
+#define OCT_PACK_CONV_FPROP 0   /* (Cout,Cin,3,3): row=co,  k=(tap,ci)               */
+#define OCT_PACK_CONV_DGRAD 1   /* (Cout,Cin,3,3): row=ci,  k=(flipped tap,co)       */
+#define OCT_PACK_DECONV_FPROP 2 /* (Cin,Cout,2,2): row=(dydx,co), k=ci               */
+#define OCT_PACK_DECONV_DGRAD 3 /* (Cin,Cout,2,2): row=ci,  k=(dydx,co)              */
+#define OCT_PACK_1X1_DGRAD 4    /* (Cout,Cin,1,1): row=ci,  k=co                     */
+#define OCT_PACK_1X1_FPROP 5    /* (Cout,Cin,1,1): row=co,  k=ci                     */
+
+const char* oct_version_string(void);
+int oct_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf */
+int oct_get_last_error(char* buf, size_t len);
+/* number of HIP devices visible (0 on a machine without a GPU); never fails */
+int oct_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (replaces nn.Conv2d(3x3,p=1) YNet_2022.py:578-596 and
+ * nn.ConvTranspose2d(k=2,s=2) YNet_2022.py:526-540, forward and data-gradient).
+ *   fprop  3x3 : taps=9, IN_PLAIN, OUT_PLAIN, weights packed CONV_FPROP
+ *   dgrad  3x3 : taps=9, IN_PLAIN (x0 = dY), OUT_PLAIN (+split for a concat), CONV_DGRAD
+ *   deconv fwd : taps=1, IN_PLAIN, OUT_D2S (+bias),  DECONV_FPROP, cout = 4*Cout
+ *   deconv dgrd: taps=1, IN_S2D (x0 = dU at 2H x 2W), OUT_PLAIN, DECONV_DGRAD
+ * The two sources x0|x1 are a virtual torch.cat((x0,x1),1) (YNet_2022.py:557).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct OctConvDesc {
+  int dtype;         /* OCT_DT_* */
+  int n, h, w;       /* batch and GEMM pixel grid (low-res grid for S2D / D2S) */
+  int c0, c1;        /* channels of source 0 / 1 (c1 = 0: single source) */
+  int cout;          /* GEMM columns (output channels; 4*Cout for D2S) */
+  int taps;          /* 9 or 1 */
+  int xform0, xform1;
+  int in_mode, out_mode;
+  int split;         /* OUT_PLAIN: channels [0,split) -> y0, [split,cout) -> y1; 0: all to y0 */
+  int want_stats;    /* write per-workgroup partial sum / sum of squares of the fp32 outputs */
+} OctConvDesc;
+
+typedef struct OctConvArgs {
+  const void* x0; const void* x1;
+  const float* scale0; const float* shift0; /* per channel of source 0 (xform0 != NONE) */
+  const float* scale1; const float* shift1;
+  const void* wpacked;                       /* from oct_pack_weights */
+  const float* bias;                         /* D2S only, per real output channel; may be NULL */
+  void* y0; void* y1;
+  float* stat_partials;                      /* [oct_conv_stat_blocks][2][cout] fp32 */
+} OctConvArgs;
+
+/* number of partial-statistics rows oct_conv_forward writes (= spatial workgroups) */
+int oct_conv_stat_blocks(const OctConvDesc* d);
+/* elements (of the activation dtype) of the packed weight buffer for a GEMM with `rows` output
+ * rows, `taps` taps and `kch` input channels */
+size_t oct_packed_weight_elems(int rows, int taps, int kch);
+int oct_pack_weights(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, void* stream);
+int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void* stream);
+
+/* Weight gradient (replaces the autograd of the same two modules).
+ *   3x3   : taps=9, dy plain  -> dwp[tap][cout][ktot]
+ *   deconv: taps=1, dy_mode=OCT_IN_S2D (dU at 2H x 2W, cout = 4*Cout) -> dwp[0][(dydx,co)][ci]
+ * dwp must be zeroed by the caller; partial sums are accumulated with fp32 atomics.           */
+typedef struct OctWgradDesc {
+  int dtype;
+  int n, h, w;
+  int c0, c1;
+  int cout;
+  int taps;
+  int xform0, xform1;
+  int dy_mode;
+} OctWgradDesc;
+typedef struct OctWgradArgs {
+  const void* x0; const void* x1;
+  const float* scale0; const float* shift0;
+  const float* scale1; const float* shift1;
+  const void* dy;
+  float* dwp;
+} OctWgradArgs;
+int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
+/* dwp -> torch-layout gradient.  mode: OCT_PACK_CONV_FPROP (grad[co][ci][tap]),
+ * OCT_PACK_DECONV_FPROP (grad[ci][co][dydx]) or OCT_PACK_1X1_FPROP (grad[co][ci]).
+ * accumulate != 0: grad += */
+int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cout, int cin, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d in training mode (nn.BatchNorm2d, YNet_2022.py:586,598; torch defaults eps=1e-5,
+ * momentum=0.1, biased var to normalise, unbiased var into running_var).
+ * ------------------------------------------------------------------------------------------ */
+/* partials [nblocks][2][c] -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale, and
+ * running_mean/var update (skipped when running_mean == NULL).  count = N*H*W.                */
+int oct_bn_finalize(const float* partials, int nblocks, int c, double count,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var,
+                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int oct_bn_eval_coeffs(int c, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+
+/* a = relu(y*scale+shift); p = maxpool2x2(a)  (nn.MaxPool2d(2,2), YNet_2022.py:516-522) */
+int oct_bn_relu_pool_fwd(int dtype, const void* y, const float* scale, const float* shift,
+                         void* pooled, int n, int h, int w, int c, void* stream);
+/* a = relu(y*scale+shift) materialised (not used on the training path; for tests / export) */
+int oct_bn_relu_fwd(int dtype, const void* y, const float* scale, const float* shift,
+                    void* out, size_t npix, int c, void* stream);
+
+/* g = (da + route(dpool)) * [y*scale+shift > 0], written to g; partial sums of g and
+ * g*xhat (xhat = (y-mean)*invstd) per workgroup into partials[nblocks][2][c].
+ * da or dpool may be NULL (not both).  dpool is at (h/2, w/2); the gradient goes to the first
+ * maximum of each 2x2 window (ATen max_pool2d tie rule).  g may alias da.                    */
+int oct_dact_bn_reduce(int dtype, const void* da, const void* dpool, const void* y,
+                       const float* scale, const float* shift, const float* mean,
+                       const float* invstd, void* g, float* partials, int n, int h, int w, int c,
+                       void* stream);
+int oct_dact_bn_reduce_blocks(int n, int h, int w, int c, int has_pool);
+/* partials -> dgamma, dbeta and the three coefficients of dy = k[0]*g + k[1]*y + k[2]        */
+int oct_bn_bwd_finalize(const float* partials, int nblocks, int c, double count,
+                        const float* gamma, const float* mean, const float* invstd,
+                        float* dgamma, float* dbeta, float* coef /* [3][c] */, int accumulate,
+                        void* stream);
+/* dy = coef0*g + coef1*y + coef2, in place over g */
+int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, size_t npix, int c,
+                     void* stream);
+/* per-channel sum over pixels of an NHWC tensor (bias gradient of ConvTranspose2d) */
+int oct_channel_sum(int dtype, const void* x, float* out, size_t npix, int c, int accumulate,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Head: 1x1 conv + Softmax2d (YNet_2022.py:543-546,569) fused with the loss head the reference
+ * lacks: CE = nll_loss(log p) and soft Dice.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct OctHeadDesc {
+  int dtype;
+  int n, h, w;
+  int feat;      /* input channels of the 1x1 conv (init_features) */
+  int classes;   /* <= OCT_MAX_CLASSES */
+} OctHeadDesc;
+#define OCT_MAX_CLASSES 16
+#define OCT_HEAD_LOSS_SLOTS (2 + 3 * OCT_MAX_CLASSES)
+int oct_head_blocks(const OctHeadDesc* d);
+/* forward: y (NHWC dtype) -> probs (NCHW fp32, may be NULL), argmax (int64 [n,h,w], may be NULL);
+ * when target != NULL also per-workgroup loss partials [blocks][OCT_HEAD_LOSS_SLOTS].         */
+int oct_head_forward(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
+                     const float* w /* [classes][feat] */, const float* b, const int64_t* target,
+                     float* probs, int64_t* argmax, float* logits /* NCHW fp32, may be NULL */,
+                     double* loss_partials, void* stream);
+/* reduces the partials: loss_out[0..2] = total, ce, dice; dice_coef[2][classes] for backward  */
+int oct_head_loss_finalize(const OctHeadDesc* d, const double* loss_partials, int nblocks,
+                           float w_ce, float w_dice, float dice_eps, float* loss_out,
+                           float* dice_coef, void* stream);
+/* d(loss)/d(logits) as an NHWC tensor of the activation dtype [n,h,w,classes]: recomputes the
+ * logits and the softmax from y, then either dl = w_ce*(p - onehot)/N + p*(dp - <p,dp>) with the
+ * Dice term dp_c = A_c*onehot_c + B_c taken from dice_coef (fused loss path; dice_coef may be
+ * NULL), or dl = p*(dprobs - <p,dprobs>) for an explicit dprobs (NCHW fp32, autograd path).
+ * The rest of the head backward is the generic 1x1 machinery: oct_conv_forward (taps=1, weights
+ * packed OCT_PACK_1X1_DGRAD) gives dA, oct_conv_wgrad (taps=1) gives dW, oct_channel_sum db.  */
+int oct_head_dlogits(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
+                     const float* w, const float* b, const int64_t* target, const float* dice_coef,
+                     float w_ce, const float* dprobs, void* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / dtype helpers and the optimizer
+ * ------------------------------------------------------------------------------------------ */
+/* (B,C,H,W) fp32 -> (B,H,W,C) dtype */
+int oct_nchw_to_nhwc(int dtype, const float* x, void* out, int n, int c, int h, int w, void* stream);
+/* (B,H,W,C) dtype -> (B,C,H,W) fp32 (tests / export) */
+int oct_nhwc_to_nchw(int dtype, const void* x, float* out, int n, int c, int h, int w, void* stream);
+/* torch.optim.SGD (momentum, dampening 0, no nesterov): buf = mu*buf + g (buf = g when
+ * first != 0); p -= lr*buf.  grad_scale multiplies g first (1/world_size after all-reduce).  */
+int oct_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum,
+                 float weight_decay, float grad_scale, int first, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Metrics (Metrics/Region_based_metrics.py:3-61, Metrics/ConfusionMatrix_based_metrics.py:4-63)
+ * One pass over the two masks; integer inputs are reduced exactly in 64-bit with numpy's
+ * same-dtype product semantics, float inputs in fp64.
+ *   out_i[6] = { sum(t*p), sum(t), sum(p), sum((1-t)*(1-p)), sum((1-t)*p), sum(t*(1-p)) }
+ * elem: 0 u8/bool, 1 i32, 2 i64, 3 f32, 4 f64, 5 i8, 6 i16, 7 u16                                   */
+int oct_confusion_counts(const void* y_true, const void* y_pred, int elem, size_t n,
+                         int64_t* out_i /* [6] device, zeroed by callee */,
+                         double* out_f /* [6] device, zeroed by callee */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCT_HIP_H */

@@ -1,0 +1,65 @@
+"""One-pass confusion sums on the GPU (oct_confusion_counts) + host-side input normalisation."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+_ELEM = {np.dtype(np.uint8): 0, np.dtype(np.int32): 1, np.dtype(np.int64): 2, np.dtype(np.float32): 3,
+         np.dtype(np.float64): 4, np.dtype(np.int8): 5, np.dtype(np.int16): 6, np.dtype(np.uint16): 7}
+_TORCH2NP = {torch.bool: np.bool_, torch.uint8: np.uint8, torch.int8: np.int8, torch.int16: np.int16,
+             torch.int32: np.int32, torch.int64: np.int64, torch.float32: np.float32, torch.float64: np.float64,
+             torch.float16: np.float16, torch.bfloat16: np.float32}
+
+
+def _canonical(dt: np.dtype) -> np.dtype:
+    """dtype the kernel reduces in: numpy's promotion result mapped onto a supported element type."""
+    dt = np.dtype(dt)
+    if dt == np.bool_:
+        return np.dtype(np.uint8)  # bool*bool = and, 1-bool in {0,1}: identical to u8 arithmetic on {0,1}
+    if dt in _ELEM:
+        return dt
+    if dt.kind == "f":
+        return np.dtype(np.float32) if dt.itemsize < 4 else np.dtype(np.float64)
+    if dt.kind in "iu":
+        return np.dtype(np.int64)
+    raise TypeError(f"unsupported mask dtype {dt}")
+
+
+def confusion_sums(y_true, y_pred, device=None):
+    """Returns (sums, n, float32_result): sums = [tp, t, p, tn, fp, fn] as python ints (integer
+    masks, exact) or floats (float masks, fp64 accumulation)."""
+    if isinstance(y_true, torch.Tensor) or isinstance(y_pred, torch.Tensor):
+        yt = y_true if isinstance(y_true, torch.Tensor) else torch.as_tensor(np.asarray(y_true))
+        yp = y_pred if isinstance(y_pred, torch.Tensor) else torch.as_tensor(np.asarray(y_pred))
+        dev = device or (yt.device if yt.is_cuda else yp.device if yp.is_cuda else torch.device("cuda"))
+        npdt = np.result_type(_TORCH2NP[yt.dtype], _TORCH2NP[yp.dtype])
+        if yt.shape != yp.shape:
+            yt, yp = torch.broadcast_tensors(yt, yp)
+    else:
+        a, b = np.asarray(y_true), np.asarray(y_pred)
+        npdt = np.result_type(a.dtype, b.dtype)
+        if a.shape != b.shape:
+            a, b = np.broadcast_arrays(a, b)
+        dev = device or torch.device("cuda")
+        yt, yp = torch.from_numpy(np.ascontiguousarray(a)), torch.from_numpy(np.ascontiguousarray(b))
+    kdt = _canonical(npdt)
+    tdt = getattr(torch, kdt.name)
+    yt = yt.to(device=dev, dtype=tdt).contiguous()
+    yp = yp.to(device=dev, dtype=tdt).contiguous()
+    if yt.device.type != "cuda":
+        raise L.OctError("Metrics need a GPU: there is no CPU fallback on the product path")
+    n = yt.numel()
+    out_i = torch.empty(6, dtype=torch.int64, device=yt.device)
+    out_f = torch.empty(6, dtype=torch.float64, device=yt.device)
+    L.check(L.lib().oct_confusion_counts(yt.data_ptr(), yp.data_ptr(), _ELEM[kdt], n, out_i.data_ptr(),
+                                         out_f.data_ptr(), torch.cuda.current_stream().cuda_stream),
+            "oct_confusion_counts")
+    if kdt.kind == "f":
+        sums = [float(v) for v in out_f.tolist()]
+    else:
+        sums = [int(v) for v in out_i.tolist()]
+        if kdt.kind == "u":  # numpy sums unsigned arrays in uint64
+            sums = [v & 0xFFFFFFFFFFFFFFFF for v in sums]
+    return sums, n, np.dtype(npdt) == np.float32 or np.dtype(npdt) == np.float16

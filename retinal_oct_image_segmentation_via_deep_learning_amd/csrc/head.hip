@@ -1,0 +1,289 @@
+// Segmentation head: 1x1 conv + channel softmax (+ arg-max), fused with the per-pixel
+// cross-entropy / soft-Dice loss reductions, and the matching d(loss)/d(logits) kernel.
+// One thread per pixel: the 64-B NHWC feature row of a pixel is read with 16-B loads, the
+// class weights sit in LDS (broadcast reads), probabilities go out NCHW so that consecutive
+// lanes write consecutive addresses.  Loss sums are reduced wave -> workgroup -> fp64 partials.
+#include "common.h"
+
+#define HEAD_THREADS 256
+#define HEAD_MAX_FEAT 128
+
+struct HeadParams {
+  const void* y; const float* scale; const float* shift; const float* w; const float* b;
+  const int64_t* target; float* probs; int64_t* argmax; float* logits; double* loss_partials;
+  const float* dice_coef; const float* dprobs; void* dlogits; float w_ce;
+  int n, h, wd, feat, classes;
+};
+
+template <typename T, int CMAX>
+__device__ __forceinline__ void head_logits(const HeadParams& p, size_t pix, const float* sw, const float* sb,
+                                            const float* ssc, const float* ssh, float (&l)[CMAX]) {
+  const T* y = reinterpret_cast<const T*>(p.y) + pix * p.feat;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) l[c] = (c < p.classes) ? sb[c] : 0.f;
+  if ((p.feat & 7) == 0) {
+    for (int f0 = 0; f0 < p.feat; f0 += 8) {
+      float a[8];
+      load_vec<T, 8>(y + f0, a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = fmaxf(fmaf(a[j], ssc[f0 + j], ssh[f0 + j]), 0.f);
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < p.classes) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) l[c] = fmaf(sw[c * p.feat + f0 + j], a[j], l[c]);
+        }
+    }
+  } else {
+    for (int f = 0; f < p.feat; ++f) {
+      const float a = fmaxf(fmaf(to_f32(y[f]), ssc[f], ssh[f]), 0.f);
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < p.classes) l[c] = fmaf(sw[c * p.feat + f], a, l[c]);
+    }
+  }
+}
+
+template <int CMAX>
+__device__ __forceinline__ void softmax_c(int classes, const float (&l)[CMAX], float (&pr)[CMAX], float& m, float& lse) {
+  m = l[0];
+#pragma unroll
+  for (int c = 1; c < CMAX; ++c)
+    if (c < classes) m = fmaxf(m, l[c]);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    pr[c] = (c < classes) ? expf(l[c] - m) : 0.f;
+    s += pr[c];
+  }
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) pr[c] *= inv;
+  lse = logf(s);
+}
+
+__device__ __forceinline__ void head_load_consts(const HeadParams& p, float* sw, float* sb, float* ssc, float* ssh) {
+  for (int i = threadIdx.x; i < p.classes * p.feat; i += blockDim.x) sw[i] = p.w[i];
+  for (int i = threadIdx.x; i < p.classes; i += blockDim.x) sb[i] = p.b[i];
+  for (int i = threadIdx.x; i < p.feat; i += blockDim.x) { ssc[i] = p.scale[i]; ssh[i] = p.shift[i]; }
+  __syncthreads();
+}
+
+template <typename T, int CMAX>
+__global__ void __launch_bounds__(HEAD_THREADS) head_fwd_kernel(const HeadParams p) {
+  __shared__ float sw[OCT_MAX_CLASSES * HEAD_MAX_FEAT];
+  __shared__ float sb[OCT_MAX_CLASSES], ssc[HEAD_MAX_FEAT], ssh[HEAD_MAX_FEAT];
+  __shared__ double red[HEAD_THREADS / 64][OCT_HEAD_LOSS_SLOTS];
+  head_load_consts(p, sw, sb, ssc, ssh);
+  const size_t hw = (size_t)p.h * p.wd, npix = (size_t)p.n * hw;
+  float ce = 0.f, si[CMAX], sp[CMAX], sy[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) { si[c] = 0.f; sp[c] = 0.f; sy[c] = 0.f; }
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+    float l[CMAX], pr[CMAX], m, lse;
+    head_logits<T, CMAX>(p, pix, sw, sb, ssc, ssh, l);
+    softmax_c<CMAX>(p.classes, l, pr, m, lse);
+    const size_t img = pix / hw, off = pix - img * hw;
+    if (p.logits) {
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < p.classes) p.logits[(img * p.classes + c) * hw + off] = l[c];
+    }
+    if (p.probs) {
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < p.classes) p.probs[(img * p.classes + c) * hw + off] = pr[c];
+    }
+    if (p.argmax) {
+      int best = 0; float bv = pr[0];
+#pragma unroll
+      for (int c = 1; c < CMAX; ++c)
+        if (c < p.classes && pr[c] > bv) { bv = pr[c]; best = c; }  // first maximum wins (torch.argmax)
+      p.argmax[pix] = best;
+    }
+    if (p.target) {
+      const int t = (int)p.target[pix];
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        const bool hit = (c == t);
+        if (hit) ce -= (l[c] - m - lse);
+        si[c] += hit ? pr[c] : 0.f;
+        sp[c] += pr[c];
+        sy[c] += hit ? 1.f : 0.f;
+      }
+    }
+  }
+  if (p.loss_partials) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double v = wave_sum((double)ce);
+    if (lane == 0) { red[wave][0] = v; red[wave][1] = 0.0; }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      const double a = wave_sum((double)si[c]), b = wave_sum((double)sp[c]), d = wave_sum((double)sy[c]);
+      if (lane == 0) {
+        red[wave][2 + c] = a; red[wave][2 + OCT_MAX_CLASSES + c] = b; red[wave][2 + 2 * OCT_MAX_CLASSES + c] = d;
+      }
+    }
+    if (lane == 0)
+      for (int c = CMAX; c < OCT_MAX_CLASSES; ++c) {
+        red[wave][2 + c] = 0.0; red[wave][2 + OCT_MAX_CLASSES + c] = 0.0; red[wave][2 + 2 * OCT_MAX_CLASSES + c] = 0.0;
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < OCT_HEAD_LOSS_SLOTS; i += blockDim.x) {
+      double s = 0.0;
+      for (int wv = 0; wv < HEAD_THREADS / 64; ++wv) s += red[wv][i];
+      p.loss_partials[(size_t)blockIdx.x * OCT_HEAD_LOSS_SLOTS + i] = s;
+    }
+  }
+}
+
+// loss_out[0..2] = total, ce, dice.  dice_coef[0][c] = A_c, dice_coef[1][c] = B_c with
+// d(w_dice*dice)/dp_c = A_c*y_c + B_c
+__global__ void head_loss_finalize_kernel(const double* __restrict__ partials, int nblocks, int classes, double npix,
+                                          float w_ce, float w_dice, float eps, float* loss_out, float* dice_coef) {
+  __shared__ double tot[OCT_HEAD_LOSS_SLOTS];
+  for (int i = threadIdx.x; i < OCT_HEAD_LOSS_SLOTS; i += blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * OCT_HEAD_LOSS_SLOTS + i];
+    tot[i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ce = tot[0] / npix;
+    double dsum = 0.0;
+    for (int c = 0; c < classes; ++c) {
+      const double I = tot[2 + c], P = tot[2 + OCT_MAX_CLASSES + c], Y = tot[2 + 2 * OCT_MAX_CLASSES + c];
+      const double den = P + Y + (double)eps, num = 2.0 * I + (double)eps;
+      dsum += num / den;
+      dice_coef[c] = (float)(-(double)w_dice / classes * 2.0 / den);
+      dice_coef[OCT_MAX_CLASSES + c] = (float)((double)w_dice / classes * num / (den * den));
+    }
+    const double dice = 1.0 - dsum / classes;
+    loss_out[0] = (float)((double)w_ce * ce + (double)w_dice * dice);
+    loss_out[1] = (float)ce;
+    loss_out[2] = (float)dice;
+  }
+}
+
+// d(loss)/d(logits) as an NHWC tensor of the activation dtype
+template <typename T, int CMAX>
+__global__ void __launch_bounds__(HEAD_THREADS) head_dlogits_kernel(const HeadParams p) {
+  __shared__ float sw[OCT_MAX_CLASSES * HEAD_MAX_FEAT];
+  __shared__ float sb[OCT_MAX_CLASSES], ssc[HEAD_MAX_FEAT], ssh[HEAD_MAX_FEAT];
+  __shared__ float sdc[2 * OCT_MAX_CLASSES];
+  if (p.dice_coef) for (int i = threadIdx.x; i < 2 * OCT_MAX_CLASSES; i += blockDim.x) sdc[i] = p.dice_coef[i];
+  head_load_consts(p, sw, sb, ssc, ssh);
+  const size_t hw = (size_t)p.h * p.wd, npix = (size_t)p.n * hw;
+  const float inv_n = 1.f / (float)npix;
+  T* out = reinterpret_cast<T*>(p.dlogits);
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+    float l[CMAX], pr[CMAX], dp[CMAX], m, lse;
+    head_logits<T, CMAX>(p, pix, sw, sb, ssc, ssh, l);
+    softmax_c<CMAX>(p.classes, l, pr, m, lse);
+    float dl[CMAX];
+    if (p.dprobs) {
+      const size_t img = pix / hw, off = pix - img * hw;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        dp[c] = (c < p.classes) ? p.dprobs[(img * p.classes + c) * hw + off] : 0.f;
+        dot = fmaf(pr[c], dp[c], dot);
+      }
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) dl[c] = pr[c] * (dp[c] - dot);
+    } else {
+      const int t = (int)p.target[pix];
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        dp[c] = 0.f;
+        if (p.dice_coef && c < p.classes) dp[c] = (c == t ? sdc[c] : 0.f) + sdc[OCT_MAX_CLASSES + c];
+        dot = fmaf(pr[c], dp[c], dot);
+      }
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        dl[c] = p.w_ce * (pr[c] - (c == t ? 1.f : 0.f)) * inv_n + pr[c] * (dp[c] - dot);
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < p.classes) out[pix * p.classes + c] = from_f32<T>(dl[c]);
+  }
+}
+
+static int head_grid(const OctHeadDesc* d) {
+  const size_t npix = (size_t)d->n * d->h * d->w;
+  size_t b = (npix + HEAD_THREADS - 1) / HEAD_THREADS;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+extern "C" int oct_head_blocks(const OctHeadDesc* d) { return d ? head_grid(d) : 0; }
+
+static int head_check(const OctHeadDesc* d, const char* who) {
+  OCT_CHECK(d, "%s: null descriptor", who);
+  OCT_CHECK(d->dtype == OCT_DT_BF16 || d->dtype == OCT_DT_F32, "%s: bad dtype %d", who, d->dtype);
+  OCT_CHECK(d->n > 0 && d->h > 0 && d->w > 0, "%s: bad shape", who);
+  OCT_CHECK(d->feat > 0 && d->feat <= HEAD_MAX_FEAT, "%s: feat %d not in [1,%d]", who, d->feat, HEAD_MAX_FEAT);
+  OCT_CHECK(d->classes > 0 && d->classes <= OCT_MAX_CLASSES, "%s: classes %d not in [1,%d]", who, d->classes, OCT_MAX_CLASSES);
+  return OCT_OK;
+}
+
+#define HEAD_DISPATCH(KERNEL, d, grid, s, p)                                                           \
+  do {                                                                                                 \
+    const int cm = (d)->classes <= 2 ? 2 : (d)->classes <= 4 ? 4 : (d)->classes <= 8 ? 8 : 16;         \
+    if ((d)->dtype == OCT_DT_BF16) {                                                                   \
+      if (cm == 2) hipLaunchKernelGGL((KERNEL<bf16_t, 2>), dim3(grid), dim3(HEAD_THREADS), 0, s, p);   \
+      else if (cm == 4) hipLaunchKernelGGL((KERNEL<bf16_t, 4>), dim3(grid), dim3(HEAD_THREADS), 0, s, p); \
+      else if (cm == 8) hipLaunchKernelGGL((KERNEL<bf16_t, 8>), dim3(grid), dim3(HEAD_THREADS), 0, s, p); \
+      else hipLaunchKernelGGL((KERNEL<bf16_t, 16>), dim3(grid), dim3(HEAD_THREADS), 0, s, p);          \
+    } else {                                                                                           \
+      if (cm == 2) hipLaunchKernelGGL((KERNEL<float, 2>), dim3(grid), dim3(HEAD_THREADS), 0, s, p);    \
+      else if (cm == 4) hipLaunchKernelGGL((KERNEL<float, 4>), dim3(grid), dim3(HEAD_THREADS), 0, s, p); \
+      else if (cm == 8) hipLaunchKernelGGL((KERNEL<float, 8>), dim3(grid), dim3(HEAD_THREADS), 0, s, p); \
+      else hipLaunchKernelGGL((KERNEL<float, 16>), dim3(grid), dim3(HEAD_THREADS), 0, s, p);           \
+    }                                                                                                  \
+  } while (0)
+
+extern "C" int oct_head_forward(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
+                                const float* w, const float* b, const int64_t* target, float* probs,
+                                int64_t* argmax, float* logits, double* loss_partials, void* stream) {
+  int rc = head_check(d, "oct_head_forward");
+  if (rc) return rc;
+  OCT_CHECK(y && scale && shift && w && b, "oct_head_forward: null pointer");
+  OCT_CHECK(!(loss_partials && !target), "oct_head_forward: loss partials need a target");
+  HeadParams p = {};
+  p.y = y; p.scale = scale; p.shift = shift; p.w = w; p.b = b; p.target = target; p.probs = probs;
+  p.argmax = argmax; p.logits = logits; p.loss_partials = target ? loss_partials : nullptr;
+  p.n = d->n; p.h = d->h; p.wd = d->w; p.feat = d->feat; p.classes = d->classes;
+  if (!loss_partials) p.target = nullptr;
+  const int grid = head_grid(d);
+  hipStream_t s = as_stream(stream);
+  HEAD_DISPATCH(head_fwd_kernel, d, grid, s, p);
+  return oct_check_launch("head_fwd");
+}
+
+extern "C" int oct_head_loss_finalize(const OctHeadDesc* d, const double* loss_partials, int nblocks, float w_ce,
+                                      float w_dice, float dice_eps, float* loss_out, float* dice_coef, void* stream) {
+  int rc = head_check(d, "oct_head_loss_finalize");
+  if (rc) return rc;
+  OCT_CHECK(loss_partials && loss_out && dice_coef && nblocks > 0, "oct_head_loss_finalize: bad args");
+  hipLaunchKernelGGL(head_loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), loss_partials, nblocks,
+                     d->classes, (double)d->n * d->h * d->w, w_ce, w_dice, dice_eps, loss_out, dice_coef);
+  return oct_check_launch("head_loss_finalize");
+}
+
+extern "C" int oct_head_dlogits(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
+                                const float* w, const float* b, const int64_t* target, const float* dice_coef,
+                                float w_ce, const float* dprobs, void* dlogits, void* stream) {
+  int rc = head_check(d, "oct_head_dlogits");
+  if (rc) return rc;
+  OCT_CHECK(y && scale && shift && w && b && dlogits, "oct_head_dlogits: null pointer");
+  OCT_CHECK(target || dprobs, "oct_head_dlogits: need a target or dprobs");
+  HeadParams p = {};
+  p.y = y; p.scale = scale; p.shift = shift; p.w = w; p.b = b; p.target = target; p.dice_coef = dice_coef;
+  p.dprobs = dprobs; p.dlogits = dlogits; p.w_ce = w_ce;
+  p.n = d->n; p.h = d->h; p.wd = d->w; p.feat = d->feat; p.classes = d->classes;
+  const int grid = head_grid(d);
+  hipStream_t s = as_stream(stream);
+  HEAD_DISPATCH(head_dlogits_kernel, d, grid, s, p);
+  return oct_check_launch("head_dlogits");
+}

@@ -1,0 +1,251 @@
+// Weight gradient of the 3x3 convolution / 2x2 transposed convolution on MFMA (gfx950).
+//
+//   dW[tap][co][ci] = sum over pixels  dY[p][co] * A[p + tap][ci]
+//
+// The contraction runs over PIXELS, so both operands are needed "pixel-major per channel".
+// A workgroup stages a TH x 32 tile of dY and the matching halo tile of the (BN+ReLU-transformed,
+// virtually concatenated) input in LDS, [pixel][channel] like the forward kernel, and each wave
+// gathers its fragments pixel-strided out of those tiles.  Every wave owns one 32(co) x 32(ci)
+// block and keeps all TAPS accumulators (9 x 16 registers) resident while the workgroup walks
+// its share of the image tiles (persistent loop): the cross-workgroup reduction happens once per
+// workgroup, as fp32 atomics into dwp[tap][co][ci] whose lanes run along ci (128-B segments).
+#include "common.h"
+
+struct WgradParams {
+  const void* x0; const void* x1;
+  const float* sc0; const float* sh0; const float* sc1; const float* sh1;
+  const void* dy; float* dwp;
+  int n, h, w;
+  int c0, c1, ktot;
+  int cout;            // GEMM rows (4*Cout for the deconv)
+  int xf0, xf1, dy_mode;
+  int tiles_x, tiles_y, ntiles;
+};
+
+template <typename T>
+__device__ __forceinline__ float wg_fetch_in(const WgradParams& p, size_t pix, int k) {
+  if (k >= p.ktot) return 0.f;
+  if (k < p.c0) {
+    float v = to_f32(reinterpret_cast<const T*>(p.x0)[pix * p.c0 + k]);
+    if (p.xf0) v = fmaxf(fmaf(v, p.sc0[k], p.sh0[k]), 0.f);
+    return v;
+  }
+  const int c = k - p.c0;
+  float v = to_f32(reinterpret_cast<const T*>(p.x1)[pix * p.c1 + c]);
+  if (p.xf1) v = fmaxf(fmaf(v, p.sc1[c], p.sh1[c]), 0.f);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void wg_fetch_in8(const WgradParams& p, size_t pix, int k, float (&v)[8]) {
+  const T* src = nullptr; const float* sc = nullptr; const float* sh = nullptr; int c = 0, cs = 0; bool xf = false;
+  if ((p.c0 & 7) == 0 && k + 8 <= p.c0) {
+    src = reinterpret_cast<const T*>(p.x0); c = k; cs = p.c0; sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0;
+  } else if ((p.c0 & 7) == 0 && (p.c1 & 7) == 0 && k >= p.c0 && k + 8 <= p.ktot) {
+    src = reinterpret_cast<const T*>(p.x1); c = k - p.c0; cs = p.c1; sc = p.sc1; sh = p.sh1; xf = p.xf1 != 0;
+  }
+  if (src) {
+    load_vec<T, 8>(src + pix * cs + c, v);
+    if (xf) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[c + j], sh[c + j]), 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = wg_fetch_in<T>(p, pix, k + j);
+  }
+}
+
+// dY element: GEMM row `row` of GEMM pixel (img, y, x)
+template <typename T>
+__device__ __forceinline__ void wg_fetch_dy8(const WgradParams& p, int img, int y, int x, int row, float (&v)[8]) {
+  const T* dy = reinterpret_cast<const T*>(p.dy);
+  if (p.dy_mode == OCT_IN_S2D) {
+    const int cr = p.cout >> 2;
+    if ((cr & 7) == 0 && row + 8 <= p.cout) {
+      const int dydx = row / cr, co = row - dydx * cr;
+      const size_t pix = ((size_t)img * (2 * p.h) + (2 * y + (dydx >> 1))) * (size_t)(2 * p.w) + (2 * x + (dydx & 1));
+      load_vec<T, 8>(dy + pix * cr + co, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rr = row + j;
+        if (rr < p.cout) {
+          const int dydx = rr / cr, co = rr - dydx * cr;
+          const size_t pix = ((size_t)img * (2 * p.h) + (2 * y + (dydx >> 1))) * (size_t)(2 * p.w) + (2 * x + (dydx & 1));
+          v[j] = to_f32(dy[pix * cr + co]);
+        } else {
+          v[j] = 0.f;
+        }
+      }
+    }
+    return;
+  }
+  const size_t pix = ((size_t)img * p.h + y) * (size_t)p.w + x;
+  if ((p.cout & 7) == 0 && row + 8 <= p.cout) {
+    load_vec<T, 8>(dy + pix * p.cout + row, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (row + j < p.cout) ? to_f32(dy[pix * p.cout + row + j]) : 0.f;
+  }
+}
+
+template <typename T, int TAPS>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr int PIXE = 32 + 8 / (int)sizeof(T) * 2;  // elements per LDS pixel: 32 channels + pad (keeps 16-B rows)
+  typedef Mma<T> M;
+  typedef typename M::Frag Frag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* in_tile = reinterpret_cast<T*>(smem);                 // [LH*LW][PIXE]
+  T* dy_tile = in_tile + LH * LW * PIXE;                   // [TH*TW][PIXE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int bx = tile;
+    const int txi = bx % p.tiles_x; bx /= p.tiles_x;
+    const int tyi = bx % p.tiles_y; const int img = bx / p.tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    __syncthreads();
+    for (int idx = tid; idx < LH * LW * 4; idx += 256) {
+      const int pix = idx >> 2, grp = idx & 3;
+      const int ly = pix / LW, lx = pix - ly * LW;
+      const int iy = y0 + ly - HALO, ix = x0 + lx - HALO;
+      float v[8];
+      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
+        wg_fetch_in8<T>(p, ((size_t)img * p.h + iy) * (size_t)p.w + ix, ci0 + grp * 8, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      store_vec<T, 8>(in_tile + pix * PIXE + grp * 8, v);
+    }
+    for (int idx = tid; idx < TH * TW * 4; idx += 256) {
+      const int pix = idx >> 2, grp = idx & 3;
+      const int ly = pix / TW, lx = pix - ly * TW;
+      const int oy = y0 + ly, ox = x0 + lx;
+      float v[8];
+      if (oy < p.h && ox < p.w) {
+        wg_fetch_dy8<T>(p, img, oy, ox, co0 + grp * 8, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      store_vec<T, 8>(dy_tile + pix * PIXE + grp * 8, v);
+    }
+    __syncthreads();
+    // each wave: tile rows {2*wave, 2*wave+1}, two 16-pixel k-steps per row
+#pragma unroll 1
+    for (int step = 0; step < 4; ++step) {
+      const int row = wave * 2 + (step >> 1);
+      const int xs = (step & 1) * 16 + 8 * hh;  // first of this lane's 8 pixels
+      Frag a = M::zero();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) M::set(a, j, dy_tile[(row * TW + xs + j) * PIXE + r]);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
+        Frag b = M::zero();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) M::set(b, j, in_tile[((row + ty) * LW + xs + j + tx) * PIXE + r]);
+        M::mma(acc[t], a, b);
+      }
+    }
+  }
+  // D[row = co][col = ci]: reg i -> co = co0 + (i&3) + 8*(i>>2) + 4*hh ; lane -> ci = ci0 + r
+  const int ci = ci0 + r;
+  if (ci < p.ktot) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (co < p.cout) atomicAdd(&p.dwp[((size_t)t * p.cout + co) * p.ktot + ci], acc[t][i]);
+      }
+  }
+}
+
+extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
+  OCT_CHECK(d && a, "oct_conv_wgrad: null descriptor");
+  OCT_CHECK(d->dtype == OCT_DT_BF16 || d->dtype == OCT_DT_F32, "oct_conv_wgrad: bad dtype %d", d->dtype);
+  OCT_CHECK(d->taps == 9 || d->taps == 1, "oct_conv_wgrad: taps must be 9 or 1");
+  OCT_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->c0 > 0 && d->c1 >= 0 && d->cout > 0, "oct_conv_wgrad: bad shape");
+  OCT_CHECK(a->x0 && a->dy && a->dwp, "oct_conv_wgrad: null tensor");
+  OCT_CHECK(d->c1 == 0 || a->x1, "oct_conv_wgrad: c1 > 0 but x1 is null");
+  OCT_CHECK(!(d->dy_mode == OCT_IN_S2D && (d->cout & 3)), "oct_conv_wgrad: S2D dy needs cout %% 4 == 0");
+  OCT_CHECK(!(d->xform0 && (!a->scale0 || !a->shift0)), "oct_conv_wgrad: xform0 without scale/shift");
+  OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
+  WgradParams p;
+  p.x0 = a->x0; p.x1 = a->x1; p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
+  p.dy = a->dy; p.dwp = a->dwp;
+  p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.ktot = d->c0 + d->c1; p.cout = d->cout;
+  p.xf0 = d->xform0; p.xf1 = d->xform1; p.dy_mode = d->dy_mode;
+  p.tiles_x = ceil_div(d->w, 32); p.tiles_y = ceil_div(d->h, 8); p.ntiles = p.tiles_x * p.tiles_y * d->n;
+  const int nco = ceil_div(d->cout, 32), nci = ceil_div(p.ktot, 32);
+  // persistent workgroups: ~4 per CU over all channel-block pairs
+  int per_pair = 1024 / (nco * nci);
+  if (per_pair < 1) per_pair = 1;
+  if (per_pair > p.ntiles) per_pair = p.ntiles;
+  dim3 grid(per_pair, nco, nci);
+  const int halo = d->taps == 9 ? 1 : 0;
+  const int esz = d->dtype == OCT_DT_BF16 ? 2 : 4;
+  const int pixe = 32 + 8 / esz * 2;
+  const size_t lds = (size_t)((8 + 2 * halo) * (32 + 2 * halo) + 8 * 32) * pixe * esz;
+  hipStream_t s = as_stream(stream);
+  if (d->dtype == OCT_DT_BF16) {
+    if (d->taps == 9) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 9>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1>), grid, dim3(256), lds, s, p);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, 9>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      attr_set = true;
+    }
+    if (d->taps == 9) hipLaunchKernelGGL((wgrad_kernel<float, 9>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<float, 1>), grid, dim3(256), lds, s, p);
+  }
+  return oct_check_launch("wgrad");
+}
+
+// dwp[tap][rows][kch] -> torch-layout gradient
+__global__ void unpack_wgrad_kernel(int mode, const float* __restrict__ dwp, float* __restrict__ grad, int cout,
+                                    int cin, int accumulate, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float v;
+    if (mode == OCT_PACK_CONV_FPROP) {  // grad[co][ci][tap]
+      const int tap = i % 9; const size_t r = i / 9; const int ci = r % cin; const int co = r / cin;
+      v = dwp[((size_t)tap * cout + co) * cin + ci];
+    } else if (mode == OCT_PACK_DECONV_FPROP) {  // grad[ci][co][dydx] ; dwp[0][dydx*cout+co][ci]
+      const int dydx = i & 3; const size_t r = i >> 2; const int co = r % cout; const int ci = r / cout;
+      v = dwp[((size_t)dydx * cout + co) * cin + ci];
+    } else {  // 1x1: grad[co][ci] = dwp[0][co][ci]
+      v = dwp[i];
+    }
+    grad[i] = accumulate ? grad[i] + v : v;
+  }
+}
+
+extern "C" int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cout, int cin, int accumulate, void* stream) {
+  OCT_CHECK(mode == OCT_PACK_CONV_FPROP || mode == OCT_PACK_DECONV_FPROP || mode == OCT_PACK_1X1_FPROP,
+            "oct_unpack_wgrad: bad mode %d", mode);
+  OCT_CHECK(dwp && grad && cout > 0 && cin > 0, "oct_unpack_wgrad: bad arguments");
+  const size_t total = (size_t)cout * cin * (mode == OCT_PACK_CONV_FPROP ? 9 : mode == OCT_PACK_DECONV_FPROP ? 4 : 1);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), mode, dwp, grad, cout, cin,
+                     accumulate, total);
+  return oct_check_launch("unpack_wgrad");
+}

@@ -1,0 +1,371 @@
+"""Kernel schedule of the U-Net training path on one MI355X.
+
+Host-side plumbing only: tensors come from PyTorch's caching allocator, every arithmetic step is
+a call into liboct_hip.so (include/oct_hip.h) on torch's current HIP stream.  The network it
+runs is the reference's UNet (SOTAS/Lesions_Segment/YNet_2022.py:509-602): four encoder blocks,
+bottleneck, four decoder blocks with ConvTranspose2d up-sampling and (dec, enc) concatenation,
+1x1 head + channel softmax.
+
+Data layout in HBM
+  activations : NHWC, bf16 (production) or fp32 (parity mode); only RAW conv outputs are stored.
+                BatchNorm-apply + ReLU are never materialised -- the consumer conv applies
+                a = max(y*scale+shift, 0) while staging its input tile; torch.cat is virtual
+                (the consumer reads two base pointers); max-pool output is the one extra tensor.
+  parameters  : fp32, torch layout (state_dict compatible); re-packed into MFMA fragment order
+                (activation dtype) whenever they change.
+  gradients   : activation gradients in the activation dtype, parameter gradients fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# (module attribute, layer-name prefix) in forward order -- YNet_2022.py:514-540
+ENC = [("encoder1", "enc1"), ("encoder2", "enc2"), ("encoder3", "enc3"), ("encoder4", "enc4")]
+BOTT = ("bottleneck", "bottleneck")
+DEC = [("decoder4", "dec4"), ("decoder3", "dec3"), ("decoder2", "dec2"), ("decoder1", "dec1")]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class Src:
+    """Input of a conv: up to two NHWC tensors (virtual concat) with optional BN+ReLU on load."""
+    x0: torch.Tensor
+    c0: int
+    bn0: "BNState | None" = None
+    x1: torch.Tensor | None = None
+    c1: int = 0
+    bn1: "BNState | None" = None
+
+    @property
+    def channels(self) -> int:
+        return self.c0 + self.c1
+
+
+@dataclass
+class BNState:
+    scale: torch.Tensor
+    shift: torch.Tensor
+    mean: torch.Tensor | None = None
+    invstd: torch.Tensor | None = None
+
+
+@dataclass
+class ConvRec:
+    """What backward needs about one conv+BN(+ReLU) layer."""
+    wkey: str
+    gkey: str
+    bkey: str
+    src: Src
+    y: torch.Tensor
+    bn: BNState
+    cout: int
+    n: int
+    h: int
+    w: int
+
+
+@dataclass
+class Ctx:
+    n: int = 0
+    h: int = 0
+    w: int = 0
+    convs: dict = field(default_factory=dict)   # level -> [ConvRec conv1, ConvRec conv2]
+    ups: dict = field(default_factory=dict)     # k -> (input ConvRec, u tensor)
+    head_in: ConvRec | None = None
+    target: torch.Tensor | None = None
+    dice_coef: torch.Tensor | None = None
+    loss: torch.Tensor | None = None
+    loss_cfg: tuple = (1.0, 0.0, 1e-7)
+
+
+class UNetEngine:
+    def __init__(self, in_channels: int, out_channels: int, features: int, dtype: str = "bf16"):
+        if out_channels > L.MAX_CLASSES:
+            raise L.OctError(f"out_channels={out_channels} exceeds the head kernel's limit {L.MAX_CLASSES}")
+        self.cin, self.ncls, self.f = in_channels, out_channels, features
+        self.set_dtype(dtype)
+        self._packed = {}  # (key, mode) -> (version, tensor)
+
+    def set_dtype(self, dtype: str) -> None:
+        if dtype not in ("bf16", "f32"):
+            raise ValueError("dtype must be 'bf16' or 'f32'")
+        self.dtype = dtype
+        self.dt = L.DT_BF16 if dtype == "bf16" else L.DT_F32
+        self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self._packed = {}
+
+    # ---- small helpers --------------------------------------------------------------------------
+    def _act(self, n, h, w, c, dev):
+        return torch.empty((n, h, w, c), dtype=self.tdt, device=dev)
+
+    def _pack(self, key: str, wt: torch.Tensor, mode: int, cout: int, cin: int) -> torch.Tensor:
+        # packed copies are reused until the parameter changes: torch bumps _version on in-place
+        # updates, our own raw-pointer optimizer bumps L.param_generation
+        ver = (wt._version, L.param_generation[0])
+        hit = self._packed.get((key, mode))
+        if hit is not None and hit[0] == ver and hit[2] == wt.data_ptr():
+            return hit[1]
+        rows, taps, kch = {
+            L.PACK_CONV_FPROP: (cout, 9, cin), L.PACK_CONV_DGRAD: (cin, 9, cout),
+            L.PACK_DECONV_FPROP: (4 * cout, 1, cin), L.PACK_DECONV_DGRAD: (cin, 1, 4 * cout),
+            L.PACK_1X1_DGRAD: (cin, 1, cout), L.PACK_1X1_FPROP: (cout, 1, cin)}[mode]
+        elems = L.lib().oct_packed_weight_elems(rows, taps, kch)
+        out = hit[1] if hit is not None else torch.empty(elems, dtype=self.tdt, device=wt.device)
+        L.check(L.lib().oct_pack_weights(mode, self.dt, wt.data_ptr(), out.data_ptr(), cout, cin, _stream()),
+                "oct_pack_weights")
+        self._packed[(key, mode)] = (ver, out, wt.data_ptr())
+        return out
+
+    def _conv(self, src: Src, wpacked, cout, taps, n, h, w, y0, *, y1=None, split=0, in_mode=L.IN_PLAIN,
+              out_mode=L.OUT_PLAIN, bias=None, stats=None):
+        d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
+                       L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
+                       L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE,
+                       in_mode, out_mode, split, 1 if stats is not None else 0)
+        a = L.ConvArgs(L.ptr(src.x0), L.ptr(src.x1),
+                       L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
+                       L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
+                       L.ptr(wpacked), L.ptr(bias), L.ptr(y0), L.ptr(y1), L.ptr(stats))
+        L.check(L.lib().oct_conv_forward(C.byref(d), C.byref(a), _stream()), "oct_conv_forward")
+
+    def _stat_blocks(self, cout, n, h, w):
+        d = L.ConvDesc(self.dt, n, h, w, 1, 0, cout, 9, 0, 0, 0, 0, 0, 1)
+        return L.lib().oct_conv_stat_blocks(C.byref(d))
+
+    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN):
+        ktot = src.channels
+        dwp = torch.zeros((taps, cout, ktot), dtype=torch.float32, device=dy.device)
+        d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
+                        L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
+                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, dy_mode)
+        a = L.WgradArgs(L.ptr(src.x0), L.ptr(src.x1),
+                        L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
+                        L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
+                        L.ptr(dy), L.ptr(dwp))
+        L.check(L.lib().oct_conv_wgrad(C.byref(d), C.byref(a), _stream()), "oct_conv_wgrad")
+        return dwp
+
+    def _unpack(self, mode, dwp, grad, cout, cin, accumulate):
+        L.check(L.lib().oct_unpack_wgrad(mode, dwp.data_ptr(), grad.data_ptr(), cout, cin, int(accumulate),
+                                         _stream()), "oct_unpack_wgrad")
+
+    # ---- forward --------------------------------------------------------------------------------
+    def _conv_bn(self, P, mod, pre, i, src: Src, cout, n, h, w, train: bool, ctx: Ctx | None) -> ConvRec:
+        wkey = f"{mod}.{pre}conv{i}.weight"
+        nk = f"{mod}.{pre}norm{i}"
+        wt = P[wkey]
+        dev = wt.device
+        wp = self._pack(wkey, wt, L.PACK_CONV_FPROP, cout, src.channels)
+        y = self._act(n, h, w, cout, dev)
+        scale = torch.empty(cout, dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        if train:
+            nblk = self._stat_blocks(cout, n, h, w)
+            partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
+            self._conv(src, wp, cout, 9, n, h, w, y, stats=partials)
+            mean = torch.empty_like(scale)
+            invstd = torch.empty_like(scale)
+            L.check(L.lib().oct_bn_finalize(
+                partials.data_ptr(), nblk, cout, float(n * h * w), P[nk + ".weight"].data_ptr(),
+                P[nk + ".bias"].data_ptr(), BN_EPS, BN_MOMENTUM, P[nk + ".running_mean"].data_ptr(),
+                P[nk + ".running_var"].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                shift.data_ptr(), _stream()), "oct_bn_finalize")
+            P[nk + ".num_batches_tracked"].add_(1)
+            bn = BNState(scale, shift, mean, invstd)
+        else:
+            self._conv(src, wp, cout, 9, n, h, w, y)
+            L.check(L.lib().oct_bn_eval_coeffs(
+                cout, P[nk + ".weight"].data_ptr(), P[nk + ".bias"].data_ptr(),
+                P[nk + ".running_mean"].data_ptr(), P[nk + ".running_var"].data_ptr(), BN_EPS,
+                scale.data_ptr(), shift.data_ptr(), _stream()), "oct_bn_eval_coeffs")
+            bn = BNState(scale, shift)
+        return ConvRec(wkey, nk + ".weight", nk + ".bias", src, y, bn, cout, n, h, w)
+
+    def _block(self, P, level, names, src, cout, n, h, w, train, ctx):
+        mod, pre = names
+        r1 = self._conv_bn(P, mod, pre, 1, src, cout, n, h, w, train, ctx)
+        r2 = self._conv_bn(P, mod, pre, 2, Src(r1.y, cout, r1.bn), cout, n, h, w, train, ctx)
+        ctx.convs[level] = [r1, r2]
+        return r2
+
+    def forward(self, P: dict, x: torch.Tensor, train: bool, target: torch.Tensor | None = None,
+                loss_cfg=(1.0, 0.0, 1e-7), want_probs=True, want_argmax=False, want_logits=False):
+        """P: name -> fp32 device tensor with the reference's state_dict keys.
+        Returns (ctx, probs|None, argmax|None, logits|None)."""
+        lib = L.lib()
+        if x.dim() != 4 or x.shape[1] != self.cin:
+            raise RuntimeError(f"expected input (B,{self.cin},H,W), got {tuple(x.shape)}")
+        n, _, h, w = x.shape
+        if h % 16 or w % 16:
+            # same failure the reference hits at torch.cat, YNet_2022.py:557
+            raise RuntimeError(
+                f"Sizes of tensors must match except in dimension 1. Input {h}x{w} is not divisible by 16 "
+                "(four 2x2 poolings followed by four 2x up-samplings)")
+        dev = x.device
+        if dev.type != "cuda":
+            raise L.OctError("the HIP path needs a device tensor (there is no CPU fallback)")
+        xf = x.detach().to(torch.float32).contiguous()
+        ctx = Ctx(n=n, h=h, w=w, loss_cfg=tuple(loss_cfg))
+        xt = self._act(n, h, w, self.cin, dev)
+        L.check(lib.oct_nchw_to_nhwc(self.dt, xf.data_ptr(), xt.data_ptr(), n, self.cin, h, w, _stream()),
+                "oct_nchw_to_nhwc")
+        src = Src(xt, self.cin)
+        f = self.f
+        hh, ww = h, w
+        skips = {}
+        for li, names in enumerate(ENC):
+            cout = f << li
+            r2 = self._block(P, names[1], names, src, cout, n, hh, ww, train, ctx)
+            skips[li + 1] = r2
+            pooled = self._act(n, hh // 2, ww // 2, cout, dev)
+            L.check(lib.oct_bn_relu_pool_fwd(self.dt, r2.y.data_ptr(), r2.bn.scale.data_ptr(),
+                                             r2.bn.shift.data_ptr(), pooled.data_ptr(), n, hh, ww, cout,
+                                             _stream()), "oct_bn_relu_pool_fwd")
+            hh //= 2
+            ww //= 2
+            src = Src(pooled, cout)
+        prev = self._block(P, "bott", BOTT, src, f * 16, n, hh, ww, train, ctx)
+        for di, names in enumerate(DEC):
+            k = 4 - di
+            cin_d, cout_d = prev.cout, prev.cout // 2
+            wkey = f"upconv{k}.weight"
+            wp = self._pack(wkey, P[wkey], L.PACK_DECONV_FPROP, cout_d, cin_d)
+            u = self._act(n, hh * 2, ww * 2, cout_d, dev)
+            self._conv(Src(prev.y, cin_d, prev.bn), wp, 4 * cout_d, 1, n, hh, ww, u, out_mode=L.OUT_D2S,
+                       bias=P[f"upconv{k}.bias"])
+            ctx.ups[k] = (prev, u)
+            hh *= 2
+            ww *= 2
+            sk = skips[k]
+            src = Src(u, cout_d, None, sk.y, sk.cout, sk.bn)
+            prev = self._block(P, names[1], names, src, cout_d, n, hh, ww, train, ctx)
+        ctx.head_in = prev
+        hd = L.HeadDesc(self.dt, n, h, w, f, self.ncls)
+        probs = torch.empty((n, self.ncls, h, w), dtype=torch.float32, device=dev) if want_probs else None
+        amax = torch.empty((n, h, w), dtype=torch.int64, device=dev) if want_argmax else None
+        logits = torch.empty((n, self.ncls, h, w), dtype=torch.float32, device=dev) if want_logits else None
+        partials = None
+        if target is not None:
+            if target.shape != (n, h, w):
+                raise RuntimeError(f"target must be (B,H,W)={n, h, w}, got {tuple(target.shape)}")
+            target = target.to(device=dev, dtype=torch.int64).contiguous()
+            nb = lib.oct_head_blocks(C.byref(hd))
+            partials = torch.empty((nb, L.HEAD_LOSS_SLOTS), dtype=torch.float64, device=dev)
+        L.check(lib.oct_head_forward(C.byref(hd), prev.y.data_ptr(), prev.bn.scale.data_ptr(),
+                                     prev.bn.shift.data_ptr(), P["conv.weight"].data_ptr(),
+                                     P["conv.bias"].data_ptr(), L.ptr(target), L.ptr(probs), L.ptr(amax),
+                                     L.ptr(logits), L.ptr(partials), _stream()), "oct_head_forward")
+        if target is not None:
+            w_ce, w_dice, eps = loss_cfg
+            ctx.target = target
+            ctx.loss = torch.empty(3, dtype=torch.float32, device=dev)
+            ctx.dice_coef = torch.zeros(2 * L.MAX_CLASSES, dtype=torch.float32, device=dev)
+            L.check(lib.oct_head_loss_finalize(C.byref(hd), partials.data_ptr(), partials.shape[0], w_ce, w_dice,
+                                               eps, ctx.loss.data_ptr(), ctx.dice_coef.data_ptr(), _stream()),
+                    "oct_head_loss_finalize")
+        return ctx, probs, amax, logits
+
+    # ---- backward -------------------------------------------------------------------------------
+    def _bn_backward(self, rec: ConvRec, da, dpool, G, accumulate):
+        """da (and/or pooled gradient) wrt relu(bn(y)) -> dy in place; BN parameter grads."""
+        lib = L.lib()
+        n, h, w, c = rec.n, rec.h, rec.w, rec.cout
+        dev = rec.y.device
+        g = da if da is not None else self._act(n, h, w, c, dev)
+        nblk = lib.oct_dact_bn_reduce_blocks(n, h, w, c, 1 if dpool is not None else 0)
+        partials = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+        L.check(lib.oct_dact_bn_reduce(self.dt, L.ptr(da), L.ptr(dpool), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
+                                       rec.bn.shift.data_ptr(), rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(),
+                                       g.data_ptr(), partials.data_ptr(), n, h, w, c, _stream()),
+                "oct_dact_bn_reduce")
+        coef = torch.empty((3, c), dtype=torch.float32, device=dev)
+        L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, c, float(n * h * w), self._P[rec.gkey].data_ptr(),
+                                        rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(), G[rec.gkey].data_ptr(),
+                                        G[rec.bkey].data_ptr(), coef.data_ptr(), int(accumulate), _stream()),
+                "oct_bn_bwd_finalize")
+        L.check(lib.oct_bn_bwd_apply(self.dt, g.data_ptr(), rec.y.data_ptr(), coef.data_ptr(), n * h * w, c,
+                                     _stream()), "oct_bn_bwd_apply")
+        return g
+
+    def _conv_backward(self, rec: ConvRec, dy, G, accumulate, need_dx=True):
+        """dW of the conv (into G) and, if needed, the gradient(s) wrt its (virtually concatenated) input."""
+        n, h, w = rec.n, rec.h, rec.w
+        src = rec.src
+        cin = src.channels
+        dwp = self._wgrad(src, dy, rec.cout, 9, n, h, w)
+        self._unpack(L.PACK_CONV_FPROP, dwp, G[rec.wkey], rec.cout, cin, accumulate)
+        if not need_dx:
+            return None, None
+        wp = self._pack(rec.wkey, self._P[rec.wkey], L.PACK_CONV_DGRAD, rec.cout, cin)
+        d0 = self._act(n, h, w, src.c0, dy.device)
+        d1 = self._act(n, h, w, src.c1, dy.device) if src.c1 else None
+        self._conv(Src(dy, rec.cout), wp, cin, 9, n, h, w, d0, y1=d1, split=src.c0 if src.c1 else 0)
+        return d0, d1
+
+    def _block_backward(self, level, da, dpool, G, accumulate, need_dx=True):
+        r1, r2 = self._ctx.convs[level]
+        dy2 = self._bn_backward(r2, da, dpool, G, accumulate)
+        da1, _ = self._conv_backward(r2, dy2, G, accumulate)
+        dy1 = self._bn_backward(r1, da1, None, G, accumulate)
+        return self._conv_backward(r1, dy1, G, accumulate, need_dx=need_dx)
+
+    def backward(self, P: dict, ctx: Ctx, G: dict, dprobs: torch.Tensor | None = None, accumulate=False):
+        """Fills G (name -> fp32 grad tensor, torch layout) for every parameter.
+        dprobs=None: gradient of the fused loss recorded by forward(target=...)."""
+        lib = L.lib()
+        self._P, self._ctx = P, ctx
+        n, h, w, f, ncls = ctx.n, ctx.h, ctx.w, self.f, self.ncls
+        rec = ctx.head_in
+        dev = rec.y.device
+        hd = L.HeadDesc(self.dt, n, h, w, f, ncls)
+        dl = self._act(n, h, w, ncls, dev)
+        if dprobs is not None:
+            dprobs = dprobs.to(torch.float32).contiguous()
+            tgt, dc, w_ce = None, None, 0.0
+        else:
+            if ctx.target is None:
+                raise RuntimeError("backward without dprobs needs forward(target=...)")
+            tgt, dc, w_ce = ctx.target, ctx.dice_coef, ctx.loss_cfg[0]
+        L.check(lib.oct_head_dlogits(C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(), rec.bn.shift.data_ptr(),
+                                     P["conv.weight"].data_ptr(), P["conv.bias"].data_ptr(), L.ptr(tgt), L.ptr(dc),
+                                     w_ce, L.ptr(dprobs), dl.data_ptr(), _stream()), "oct_head_dlogits")
+        # head parameter gradients and dA through the generic 1x1 machinery
+        hsrc = Src(rec.y, f, rec.bn)
+        dwp = self._wgrad(hsrc, dl, ncls, 1, n, h, w)
+        self._unpack(L.PACK_1X1_FPROP, dwp, G["conv.weight"], ncls, f, accumulate)
+        L.check(lib.oct_channel_sum(self.dt, dl.data_ptr(), G["conv.bias"].data_ptr(), n * h * w, ncls,
+                                    int(accumulate), _stream()), "oct_channel_sum")
+        wp = self._pack("conv.weight", P["conv.weight"], L.PACK_1X1_DGRAD, ncls, f)
+        da = self._act(n, h, w, f, dev)
+        self._conv(Src(dl, ncls), wp, f, 1, n, h, w, da)
+        dskip = {}
+        for di in range(4):  # dec1, dec2, dec3, dec4
+            k = di + 1
+            du, dskip[k] = self._block_backward(f"dec{k}", da, None, G, accumulate)
+            prev, u = ctx.ups[k]
+            cin_d, cout_d = prev.cout, prev.cout // 2
+            hl, wl = prev.h, prev.w
+            L.check(lib.oct_channel_sum(self.dt, du.data_ptr(), G[f"upconv{k}.bias"].data_ptr(),
+                                        n * 4 * hl * wl, cout_d, int(accumulate), _stream()), "oct_channel_sum")
+            dwp = self._wgrad(Src(prev.y, cin_d, prev.bn), du, 4 * cout_d, 1, n, hl, wl, dy_mode=L.IN_S2D)
+            self._unpack(L.PACK_DECONV_FPROP, dwp, G[f"upconv{k}.weight"], cout_d, cin_d, accumulate)
+            wkey = f"upconv{k}.weight"
+            wp = self._pack(wkey, P[wkey], L.PACK_DECONV_DGRAD, cout_d, cin_d)
+            da = self._act(n, hl, wl, cin_d, dev)
+            self._conv(Src(du, cout_d), wp, cin_d, 1, n, hl, wl, da, in_mode=L.IN_S2D)
+        dpool, _ = self._block_backward("bott", da, None, G, accumulate)
+        for k in (4, 3, 2, 1):
+            dpool, _ = self._block_backward(f"enc{k}", dskip[k], dpool, G, accumulate, need_dx=(k != 1))
+        self._P = self._ctx = None
+        return G

@@ -1,0 +1,81 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/oct_hip.h declares
+(no compute calls here); host-side argument validation reports errors instead of throwing."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from retinal_oct_image_segmentation_via_deep_learning_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    _lib.lib()
+    return _lib
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "oct_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(oct_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    handle = C.CDLL(L.LIB_PATH)
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in oct_hip.h but not exported"
+    assert sorted(L.SIGNATURES) == syms, "python binding table out of sync with the header"
+
+
+def test_version_and_error_reporting_without_gpu(L):
+    lib = L.lib()
+    assert lib.oct_version() == 100
+    assert b"gfx950" in lib.oct_version_string()
+    assert lib.oct_device_count() >= 0
+    rc = lib.oct_conv_forward(None, None, None)
+    assert rc == -22
+    assert "null descriptor" in L.last_error()
+    d = L.ConvDesc(0, 1, 8, 8, 4, 0, 4, 9, 0, 0, 0, 0, 0, 0)
+    rc = lib.oct_conv_forward(C.byref(d), C.byref(L.ConvArgs()), None)
+    assert rc == -22 and "null tensor" in L.last_error()
+    assert lib.oct_packed_weight_elems(32, 9, 32) == 9 * 2 * 512
+    assert lib.oct_packed_weight_elems(33, 1, 17) == 2 * 2 * 512
+
+
+def test_module_api_matches_reference_without_gpu(L):
+    """constructor signature, state_dict keys/shapes, failure modes that need no device"""
+    import inspect
+
+    import numpy as np
+    import torch
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Lesions_Segment import YNet_2022 as A
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment import YNet_2022 as B
+    assert A.UNet is B.UNet
+    sig = inspect.signature(A.UNet.__init__)
+    assert [(k, v.default) for k, v in list(sig.parameters.items())[1:4]] == \
+        [("in_channels", 3), ("out_channels", 1), ("init_features", 32)]
+    gsig = inspect.signature(A.get_model)
+    assert [(k, v.default) for k, v in gsig.parameters.items()] == \
+        [("model_name", inspect._empty), ("in_channels", 1), ("num_classes", 9), ("ratio", 0.5)]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "api.npz"))
+    m = A.get_model("unet", in_channels=1, num_classes=9)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z["keys"]]
+    assert [str(list(v.shape)) for v in sd.values()] == [str(s) for s in z["shapes"]]
+    assert sum(p.numel() for p in m.parameters()) == int(z["n_params"])
+    with pytest.raises(AssertionError):
+        A.get_model("nope")
+    # seeded construction reproduces the reference's default initialisation
+    g = np.load(os.path.join(ROOT, "tests", "golden", "unet_c2_f4_1x48x64_dice.npz"))
+    torch.manual_seed(int(g["seed"]))
+    m2 = A.UNet(1, 2, init_features=4)
+    for k in ("encoder1.enc1conv1.weight", "upconv3.weight", "upconv3.bias", "conv.weight"):
+        assert np.array_equal(m2.state_dict()[k].numpy(), g["w0/" + k]), k
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m2(torch.zeros(1, 1, 32, 32))
