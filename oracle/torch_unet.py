@@ -1,0 +1,87 @@
+"""CPU oracle #2 (TEST INFRASTRUCTURE ONLY): the reference's U-Net restated on stock torch.nn.
+
+The reference's arithmetic provider IS torch: this module rebuilds the network of
+/root/reference/SOTAS/Lesions_Segment/YNet_2022.py:509-602 from its description -- same module
+names, hence the same state_dict -- and runs it with torch's own CPU kernels.  It serves as
+  * the cross-check of oracle/ref_cpu.py's hand-written backward at sizes numpy finishes slowly,
+  * the `cpu_baseline` ("port") that bench.py times on the GPU box's host cores
+    (the reference's own files cannot travel to the GPU box).
+Pinned by tests/test_oracle.py against the fixtures generated from the reference.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _stage(cin, cout, tag):
+    mods = OrderedDict()
+    for i in (1, 2):
+        mods[f"{tag}conv{i}"] = nn.Conv2d(cin if i == 1 else cout, cout, 3, padding=1, bias=False)
+        mods[f"{tag}norm{i}"] = nn.BatchNorm2d(cout)
+        mods[f"{tag}relu{i}"] = nn.ReLU(inplace=True)
+    return nn.Sequential(mods)
+
+
+class TorchUNet(nn.Module):
+    def __init__(self, in_channels=3, out_channels=1, init_features=32):
+        super().__init__()
+        f = init_features
+        widths = [f, 2 * f, 4 * f, 8 * f]
+        cin = in_channels
+        for lvl, wd in enumerate(widths, start=1):
+            setattr(self, f"encoder{lvl}", _stage(cin, wd, f"enc{lvl}"))
+            setattr(self, f"pool{lvl}", nn.MaxPool2d(2, 2))
+            cin = wd
+        self.bottleneck = _stage(8 * f, 16 * f, "bottleneck")
+        for lvl in (4, 3, 2, 1):
+            wd = widths[lvl - 1]
+            setattr(self, f"upconv{lvl}", nn.ConvTranspose2d(2 * wd, wd, 2, stride=2))
+            setattr(self, f"decoder{lvl}", _stage(2 * wd, wd, f"dec{lvl}"))
+        self.conv = nn.Conv2d(f, out_channels, 1)
+
+    def forward(self, x):
+        skips = []
+        for lvl in (1, 2, 3, 4):
+            x = getattr(self, f"encoder{lvl}")(x)
+            skips.append(x)
+            x = getattr(self, f"pool{lvl}")(x)
+        x = self.bottleneck(x)
+        for lvl in (4, 3, 2, 1):
+            x = getattr(self, f"upconv{lvl}")(x)
+            x = getattr(self, f"decoder{lvl}")(torch.cat((x, skips[lvl - 1]), dim=1))
+        return torch.softmax(self.conv(x), dim=1)
+
+
+def loss_fn(probs, target, w_ce=1.0, w_dice=0.0, eps=1e-7):
+    ce = F.nll_loss(torch.log(probs), target)
+    if w_dice == 0.0:
+        return w_ce * ce
+    onehot = F.one_hot(target, probs.shape[1]).permute(0, 3, 1, 2).to(probs.dtype)
+    inter, ps, ys = (probs * onehot).sum((0, 2, 3)), probs.sum((0, 2, 3)), onehot.sum((0, 2, 3))
+    return w_ce * ce + w_dice * (1.0 - ((2 * inter + eps) / (ps + ys + eps)).mean())
+
+
+def time_train_steps(batch, height, width, classes=8, features=32, iters=3, threads=None):
+    """B-scans/s of fwd + loss + bwd + SGD on the host cores (fp32)."""
+    import time
+    if threads:
+        torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = TorchUNet(1, classes, features).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(batch, 1, height, width, generator=g)
+    t = torch.randint(0, classes, (batch, height, width), generator=g)
+    times = []
+    for i in range(iters + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss_fn(model(x), t).backward()
+        opt.step()
+        if i:  # first iteration is warm-up
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return batch / best, best, torch.get_num_threads()

@@ -96,6 +96,8 @@ class UNetEngine:
         self.cin, self.ncls, self.f = in_channels, out_channels, features
         self.set_dtype(dtype)
         self._packed = {}  # (key, mode) -> (version, tensor)
+        self.debug = None  # set to a dict to capture intermediate gradients (tests / probes)
+        self.prof = None   # set to a list: (kind, start_event, end_event) around every MFMA launch
 
     def set_dtype(self, dtype: str) -> None:
         if dtype not in ("bf16", "f32"):
@@ -106,6 +108,19 @@ class UNetEngine:
         self._packed = {}
 
     # ---- small helpers --------------------------------------------------------------------------
+    def _prof_begin(self):
+        if self.prof is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()  # torch's current stream == the stream the kernel is launched on
+        return ev
+
+    def _prof_end(self, ev, kind):
+        if ev is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            self.prof.append((kind, ev, end))
+
     def _act(self, n, h, w, c, dev):
         return torch.empty((n, h, w, c), dtype=self.tdt, device=dev)
 
@@ -137,7 +152,9 @@ class UNetEngine:
                        L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                        L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
                        L.ptr(wpacked), L.ptr(bias), L.ptr(y0), L.ptr(y1), L.ptr(stats))
+        ev = self._prof_begin()
         L.check(L.lib().oct_conv_forward(C.byref(d), C.byref(a), _stream()), "oct_conv_forward")
+        self._prof_end(ev, "igemm")
 
     def _stat_blocks(self, cout, n, h, w):
         d = L.ConvDesc(self.dt, n, h, w, 1, 0, cout, 9, 0, 0, 0, 0, 0, 1)
@@ -153,7 +170,9 @@ class UNetEngine:
                         L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                         L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
                         L.ptr(dy), L.ptr(dwp))
+        ev = self._prof_begin()
         L.check(L.lib().oct_conv_wgrad(C.byref(d), C.byref(a), _stream()), "oct_conv_wgrad")
+        self._prof_end(ev, "wgrad")
         return dwp
 
     def _unpack(self, mode, dwp, grad, cout, cin, accumulate):
@@ -294,8 +313,14 @@ class UNetEngine:
                                         rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(), G[rec.gkey].data_ptr(),
                                         G[rec.bkey].data_ptr(), coef.data_ptr(), int(accumulate), _stream()),
                 "oct_bn_bwd_finalize")
+        if self.debug is not None:
+            self.debug["g:" + rec.wkey] = g.float().clone()
         L.check(lib.oct_bn_bwd_apply(self.dt, g.data_ptr(), rec.y.data_ptr(), coef.data_ptr(), n * h * w, c,
                                      _stream()), "oct_bn_bwd_apply")
+        if self.debug is not None:
+            self.debug["dy:" + rec.wkey] = g.float().clone()
+            self.debug["y:" + rec.wkey] = rec.y.float().clone()
+            self.debug["coef:" + rec.wkey] = coef.clone()
         return g
 
     def _conv_backward(self, rec: ConvRec, dy, G, accumulate, need_dx=True):

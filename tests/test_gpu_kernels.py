@@ -214,8 +214,9 @@ def test_bn_forward_pool_backward(env, dt, shape):
                      np.stack([y64[:, :, h // 2:].sum((0, 2, 3)), (y64[:, :, h // 2:] ** 2).sum((0, 2, 3))])])
     rm, rv = fdev(np.zeros(c)), fdev(np.ones(c))
     mean, invstd, scale, shift = (torch.empty(c, device="cuda") for _ in range(4))
-    L.check(lib.oct_bn_finalize(fdev(part).data_ptr(), 2, c, float(n * h * w), fdev(gamma).data_ptr(),
-                                fdev(beta).data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), mean.data_ptr(),
+    partd, gammad, betad = fdev(part), fdev(gamma), fdev(beta)  # keep alive: raw pointers below
+    L.check(lib.oct_bn_finalize(partd.data_ptr(), 2, c, float(n * h * w), gammad.data_ptr(),
+                                betad.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), mean.data_ptr(),
                                 invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st))
     z, rmean, rvar, rinv, xhat = O.bn_train_fwd(y64, gamma.astype(np.float64), beta.astype(np.float64))
     close(mean.cpu().numpy(), rmean, "f32", "mean", scale_tol=1e-5)
@@ -243,7 +244,7 @@ def test_bn_forward_pool_backward(env, dt, shape):
                                        g.data_ptr(), partials.data_ptr(), n, h, w, c, st))
         dgam, dbet = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
         coef = torch.empty((3, c), device="cuda")
-        L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, c, float(n * h * w), fdev(gamma).data_ptr(),
+        L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, c, float(n * h * w), gammad.data_ptr(),
                                         mean.data_ptr(), invstd.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
                                         coef.data_ptr(), 0, st))
         L.check(lib.oct_bn_bwd_apply(edt, g.data_ptr(), yd.data_ptr(), coef.data_ptr(), n * h * w, c, st))
@@ -291,9 +292,10 @@ def test_head_forward_loss_and_dlogits(env, dt, cfg):
     L.check(lib.oct_head_dlogits(C.byref(hd), yd.data_ptr(), scd.data_ptr(), shd.data_ptr(), whd.data_ptr(),
                                  bhd.data_ptr(), tg.data_ptr(), dc.data_ptr(), w_ce, None, dl.data_ptr(), st))
     dpr = rng.standard_normal((n, ncls, h, w)).astype(np.float32)
+    dprd = fdev(dpr)
     dl2 = torch.full((n, h, w, ncls), float("nan"), dtype=tdt(dt), device="cuda")
     L.check(lib.oct_head_dlogits(C.byref(hd), yd.data_ptr(), scd.data_ptr(), shd.data_ptr(), whd.data_ptr(),
-                                 bhd.data_ptr(), None, None, 0.0, fdev(dpr).data_ptr(), dl2.data_ptr(), st))
+                                 bhd.data_ptr(), None, None, 0.0, dprd.data_ptr(), dl2.data_ptr(), st))
     torch.cuda.synchronize()
     a = np.maximum(y.astype(np.float64) * sc[None, :, None, None] + sh[None, :, None, None], 0)
     rlog = np.einsum("bchw,oc->bohw", a, wh.astype(np.float64)) + bh[None, :, None, None]
@@ -316,10 +318,11 @@ def test_layout_roundtrip_and_sgd(env):
     st = torch.cuda.current_stream().cuda_stream
     rng = np.random.default_rng(9)
     x = rng.standard_normal((2, 3, 8, 16)).astype(np.float32)
+    xd = fdev(x)
     for dtn, edt in (("f32", L.DT_F32), ("bf16", L.DT_BF16)):
         t = torch.empty((2, 8, 16, 3), dtype=tdt(dtn), device="cuda")
         back = torch.empty((2, 3, 8, 16), device="cuda")
-        L.check(lib.oct_nchw_to_nhwc(edt, fdev(x).data_ptr(), t.data_ptr(), 2, 3, 8, 16, st))
+        L.check(lib.oct_nchw_to_nhwc(edt, xd.data_ptr(), t.data_ptr(), 2, 3, 8, 16, st))
         L.check(lib.oct_nhwc_to_nchw(edt, t.data_ptr(), back.data_ptr(), 2, 3, 8, 16, st))
         torch.cuda.synchronize()
         assert np.array_equal(host(t), rnd(x, dtn))
