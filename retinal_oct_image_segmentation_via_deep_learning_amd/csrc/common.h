@@ -21,6 +21,10 @@ void oct_set_error(const char* fmt, ...);
     }                                   \
   } while (0)
 int oct_check_launch(const char* what);
+// igemm2.hip: pipelined bf16 path for regular shapes (returns 1 taken / 0 not eligible / <0 error)
+int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream);
+int oct_conv_v2_stat_rows(const OctConvDesc* d);
+int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }

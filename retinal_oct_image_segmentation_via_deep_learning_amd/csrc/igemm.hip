@@ -351,6 +351,8 @@ static TileCfg pick_cfg(int cout) {
 
 extern "C" int oct_conv_stat_blocks(const OctConvDesc* d) {
   if (!d) return 0;
+  const int v2 = oct_conv_v2_stat_rows(d);
+  if (v2 >= 0) return v2;
   const TileCfg c = pick_cfg(d->cout);
   return ceil_div(d->w, 32) * ceil_div(d->h, c.th) * d->n;
 }
@@ -384,6 +386,10 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_forward: xform1 without scale/shift");
   OCT_CHECK(!(d->want_stats && !a->stat_partials), "oct_conv_forward: want_stats without buffer");
   OCT_CHECK((size_t)d->n * d->h * d->w < (1u << 31), "oct_conv_forward: too many pixels");
+  {
+    const int took = oct_conv_forward_v2(d, a, stream);
+    if (took != 0) return took < 0 ? took : OCT_OK;
+  }
   IgemmParams p;
   p.x0 = a->x0; p.x1 = a->x1; p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
   p.wp = a->wpacked; p.bias = a->bias; p.y0 = a->y0; p.y1 = a->y1;

@@ -1,0 +1,404 @@
+// Pipelined, persistent implicit-GEMM 3x3 convolution for bf16 and "regular" shapes
+// (W % 32 == 0, H % 8 == 0, every channel count a multiple of 32) -- the production path of
+// conv3x3 fprop and dgrad.  Irregular shapes and the fp32 parity mode stay on igemm.hip.
+//
+// Differences to the generic kernel, all driven by the rocprof numbers of round 1:
+//  * persistent workgroups walk a contiguous range of (tile, channel-block) items, so the halo
+//    rows shared by vertically adjacent tiles are re-read from the same XCD's L2;
+//  * the LDS halo tile is double buffered and the global loads of stage s+1 are issued BEFORE the
+//    MFMA phase of stage s (raw bf16 parked in registers, BN+ReLU applied when they are written to
+//    LDS after the phase): one barrier per stage, HBM latency hidden under the MFMAs;
+//  * WRES: for Cout <= 64 with Cin = 32 the whole filter (18 fragments = 72 VGPRs) stays resident
+//    in registers for the life of the workgroup -- no weight traffic at all in the full-resolution
+//    layers, which are HBM bound; otherwise weight fragments stream from L2 one step ahead;
+//  * epilogue: bf16 pack + v_permlane32_swap so every lane stores 16 contiguous bytes;
+//  * BatchNorm partial sums stay in registers across all tiles of the workgroup (WRES) and are
+//    reduced across lanes once.
+#include "common.h"
+#include <stdlib.h>
+
+struct Igemm2Params {
+  const bf16_t* x0; const bf16_t* x1;
+  const float* sc0; const float* sh0; const float* sc1; const float* sh1;
+  const bf16_t* wp;
+  bf16_t* y0; bf16_t* y1; float* stats;
+  int n, h, w, c0, c1, cout, split, xf0, xf1;
+  int tiles_x, tiles_y, nblk, nitems, per_wg, nch, nk16;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (bf16_t)a;
+  v[1] = (bf16_t)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf16lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS>
+__global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
+  static_assert(WM * WN == 4, "four MFMA waves");
+  constexpr int TH = WM * MF, TW = 32;
+  constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr int NPIX = LH * LW;
+  constexpr int PIXB = 80;                      // 32 bf16 + 16 B pad: conflict-free ds_read_b128
+  constexpr int BUFB = NPIX * PIXB;
+  constexpr int NSLOT = (NPIX + 31) / 32;       // producer: 32 pixels x 4 channel groups per pass
+  constexpr int NT = WN * NF * 32;
+  constexpr int KSTEPS = TAPS * 2;              // k16 steps per 32-channel chunk
+  typedef Mma<bf16_t> M;
+  typedef M::Frag Frag;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const buf0 = smem;
+  float* const wg_stats = reinterpret_cast<float*>(smem + 2 * BUFB);  // [2 parity][WM][2][NT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int it0 = blockIdx.x * p.per_wg;
+  const int it1 = min(it0 + p.per_wg, p.nitems);
+  if (it0 >= it1) return;
+  const int nstage = (it1 - it0) * p.nch;
+
+  if (wave >= 4) {
+    // =============================== producer waves (2) ===============================
+    // global -> registers (issued two stages ahead) -> BN+ReLU -> LDS halo tile of the next stage
+    const int ptid = tid - 256, grp = ptid & 3, pbase = ptid >> 2;
+    u32x4 R[NSLOT];
+    unsigned vmask = 0;
+    // per-slot constants: pixel offset relative to the tile origin and a border code
+    // (bit0 top halo row, bit1 bottom, bit2 left, bit3 right, bit4 slot beyond the tile)
+    int relp[NSLOT];
+    unsigned code[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int pix = pbase + 32 * i;
+      const int ly = pix / LW, lx = pix - ly * LW;
+      relp[i] = (ly - HALO) * p.w + (lx - HALO);
+      unsigned c = pix >= NPIX ? 16u : 0u;
+      if (HALO) c |= (ly == 0 ? 1u : 0u) | (ly == LH - 1 ? 2u : 0u) | (lx == 0 ? 4u : 0u) | (lx == LW - 1 ? 8u : 0u);
+      code[i] = c;
+    }
+    auto issue = [&](int sidx) {
+      const int item = it0 + sidx / p.nch, ch = sidx - (sidx / p.nch) * p.nch;
+      int t = item / p.nblk;
+      const int txi = t % p.tiles_x; t /= p.tiles_x;
+      const int tyi = t % p.tiles_y; const int img = t / p.tiles_y;
+      const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
+                            (txi == p.tiles_x - 1 ? 8u : 0u);
+      const size_t origin = ((size_t)img * p.h + tyi * TH) * p.w + txi * TW;
+      const bool second = ch * 32 >= p.c0;  // uniform: every 32-channel chunk lies in one source
+      const int cs = second ? p.c1 : p.c0;
+      const bf16_t* base = (second ? p.x1 + origin * p.c1 + (ch * 32 - p.c0) : p.x0 + origin * p.c0 + ch * 32) + grp * 8;
+      vmask = 0;
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if ((code[i] & edge) == 0) {
+          v = *reinterpret_cast<const u32x4*>(base + __mul24(relp[i], cs));
+          vmask |= 1u << i;
+        }
+        R[i] = v;
+      }
+    };
+    auto commit = [&](int sidx, unsigned char* buf) {
+      const int ch = sidx - (sidx / p.nch) * p.nch;
+      const int cg = ch * 32 + grp * 8;
+      const bool first = cg < p.c0;
+      const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
+      float s[8], b[8];
+      if (xf) {
+        const float* sc = first ? p.sc0 + cg : p.sc1 + (cg - p.c0);
+        const float* sh = first ? p.sh0 + cg : p.sh1 + (cg - p.c0);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh), b1 = *reinterpret_cast<const f32x4*>(sh + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] = s0[j]; s[4 + j] = s1[j]; b[j] = b0[j]; b[4 + j] = b1[j]; }
+      }
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        const int pix = pbase + 32 * i;
+        if (pix < NPIX) {
+          u32x4 v = R[i];
+          if (xf && (vmask & (1u << i))) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = fmaxf(fmaf(bf16lo(v[j]), s[2 * j], b[2 * j]), 0.f);
+              const float hi = fmaxf(fmaf(bf16hi(v[j]), s[2 * j + 1], b[2 * j + 1]), 0.f);
+              v[j] = pack_bf16x2(lo, hi);
+            }
+          }  // out-of-image pixels stay exactly zero (padding applies to the activated tensor)
+          *reinterpret_cast<u32x4*>(buf + pix * PIXB + grp * 16) = v;
+        }
+      }
+    };
+    issue(0);
+    commit(0, buf0);
+    if (nstage > 1) issue(1);
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < nstage; ++s) {
+      if (s + 1 < nstage) commit(s + 1, buf0 + (cur ^ 1) * BUFB);
+      if (s + 2 < nstage) issue(s + 2);
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (STATS && WRES) __syncthreads();  // matches the barrier of the final statistics reduction
+    return;
+  }
+
+  // ================================= MFMA waves (4) =================================
+  const int r = lane & 31, hh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  Frag wres[WRES ? KSTEPS : 1][NF];
+  if (WRES) {
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        const int nb = wn * NF + q;
+        const int tap = s >> 1, k16 = s & 1;
+        wres[s][q] = M::load(p.wp + ((size_t)(nb * TAPS + tap) * p.nk16 + k16) * 512 + lane * 8);
+      }
+  }
+
+  f32x16 acc[MF][NF];
+  float s1[STATS ? NF : 1][16], s2[STATS ? NF : 1][16];  // BN partial sums (lane = pixel column)
+  if (STATS) {
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s1[q][i] = 0.f; s2[q][i] = 0.f; }
+  }
+
+  __syncthreads();  // stage 0 is in LDS
+  int cur = 0, pending_tile = -1, pending_nbi = 0, parity = 0;
+  int item = it0, ch = 0;
+  for (int sidx = 0; sidx < nstage; ++sidx) {
+    // flush the statistics of the previous item (written to wg_stats before the last barrier)
+    if (STATS && !WRES && pending_tile >= 0) {
+      const float* ws = wg_stats + (parity ^ 1) * (WM * 2 * NT);
+      for (int i = tid; i < 2 * NT; i += 256) {
+        const int st = i / NT, cl = i - st * NT;
+        float s = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) s += ws[(w_ * 2 + st) * NT + cl];
+        p.stats[((size_t)pending_tile * 2 + st) * p.cout + pending_nbi * NT + cl] = s;
+      }
+      pending_tile = -1;
+    }
+
+    const int tile = item / p.nblk, nbi = item - tile * p.nblk;
+    if (ch == 0) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int q = 0; q < NF; ++q)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+    }
+
+    // ---- MFMA phase over the staged 32-channel chunk ----
+    {
+      const unsigned char* tb = buf0 + cur * BUFB;
+      const int nb0 = nbi * (NT / 32) + wn * NF;
+      const bf16_t* wbase = p.wp + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512 + lane * 8;
+      const size_t qstride = (size_t)TAPS * p.nk16 * 512, tstride = (size_t)p.nk16 * 512;
+      Frag wcur[NF], wnxt[NF];
+      if (!WRES) {
+#pragma unroll
+        for (int q = 0; q < NF; ++q) wcur[q] = M::load(wbase + q * qstride);
+      }
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int tap = s >> 1, k16 = s & 1;
+        const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
+        if (!WRES && s + 1 < KSTEPS) {
+          const int tap2 = (s + 1) >> 1, k2 = (s + 1) & 1;
+#pragma unroll
+          for (int q = 0; q < NF; ++q) wnxt[q] = M::load(wbase + q * qstride + tap2 * tstride + k2 * 512);
+        }
+        Frag xf[MF];
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+          xf[m] = M::load(tb + ((wm * MF + m + ty) * LW + (r + tx)) * PIXB + (k16 * 16 + 8 * hh) * 2);
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+          for (int q = 0; q < NF; ++q) M::mma(acc[m][q], WRES ? wres[s][q] : wcur[q], xf[m]);
+        if (!WRES) {
+#pragma unroll
+          for (int q = 0; q < NF; ++q) wcur[q] = wnxt[q];
+        }
+      }
+    }
+
+    // ---- epilogue of an item: NHWC stores, BN sums ----
+    if (ch == p.nch - 1) {
+      int t = tile;
+      const int txi = t % p.tiles_x; t /= p.tiles_x;
+      const int tyi = t % p.tiles_y; const int img = t / p.tiles_y;
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        const int cb0 = (nbi * (NT / 32) + wn * NF + q) * 32;
+        bf16_t* dst; int cd, co;
+        if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
+        else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          const size_t pix = ((size_t)img * p.h + tyi * TH + wm * MF + m) * p.w + txi * TW + r;
+          bf16_t* row = dst + pix * cd + co;
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            unsigned lo0 = pack_bf16x2(acc[m][q][4 * g], acc[m][q][4 * g + 1]);
+            unsigned hi0 = pack_bf16x2(acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]);
+            unsigned lo1 = pack_bf16x2(acc[m][q][4 * g + 4], acc[m][q][4 * g + 5]);
+            unsigned hi1 = pack_bf16x2(acc[m][q][4 * g + 6], acc[m][q][4 * g + 7]);
+            // lanes 32-63 of (lo0,hi0) <-> lanes 0-31 of (lo1,hi1): afterwards the lower half-wave holds
+            // channels 8g..8g+7 and the upper half-wave 8g+8..8g+15 of its pixel, 16 contiguous bytes
+            auto a = __builtin_amdgcn_permlane32_swap(lo0, lo1, false, false);
+            auto b = __builtin_amdgcn_permlane32_swap(hi0, hi1, false, false);
+            const u32x4 v = {a[0], b[0], a[1], b[1]};
+            *reinterpret_cast<u32x4*>(row + 8 * g + 8 * hh) = v;
+          }
+          if (STATS) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              s1[q][i] += acc[m][q][i];
+              s2[q][i] = fmaf(acc[m][q][i], acc[m][q][i], s2[q][i]);
+            }
+          }
+        }
+      }
+      if (STATS && !WRES) {
+        float* ws = wg_stats + parity * (WM * 2 * NT);
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+          const float t1 = reduce32_scatter16(s1[q], lane);
+          const float t2 = reduce32_scatter16(s2[q], lane);
+          if ((lane & 1) == 0) {
+            const int reg = scatter16_reg_of_lane(lane);
+            const int cl = (wn * NF + q) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            ws[(wm * 2 + 0) * NT + cl] = t1;
+            ws[(wm * 2 + 1) * NT + cl] = t2;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { s1[q][i] = 0.f; s2[q][i] = 0.f; }
+        }
+        pending_tile = tile; pending_nbi = nbi; parity ^= 1;
+      }
+    }
+
+    __syncthreads();
+    cur ^= 1;
+    if (++ch == p.nch) { ch = 0; ++item; }
+  }
+
+  // ---- final statistics ----
+  if (STATS) {
+    if (WRES) {
+      float* ws = wg_stats;
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        const float t1 = reduce32_scatter16(s1[q], lane);
+        const float t2 = reduce32_scatter16(s2[q], lane);
+        if ((lane & 1) == 0) {
+          const int reg = scatter16_reg_of_lane(lane);
+          const int cl = (wn * NF + q) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+          ws[(wm * 2 + 0) * NT + cl] = t1;
+          ws[(wm * 2 + 1) * NT + cl] = t2;
+        }
+      }
+      __syncthreads();  // the producer waves join this barrier before they exit
+      for (int i = tid; i < 2 * NT; i += 256) {
+        const int st = i / NT, cl = i - st * NT;
+        float s = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) s += ws[(w_ * 2 + st) * NT + cl];
+        if (cl < p.cout) p.stats[((size_t)blockIdx.x * 2 + st) * p.cout + cl] = s;
+      }
+    } else if (pending_tile >= 0) {
+      const float* ws = wg_stats + (parity ^ 1) * (WM * 2 * NT);
+      for (int i = tid; i < 2 * NT; i += 256) {
+        const int st = i / NT, cl = i - st * NT;
+        float s = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) s += ws[(w_ * 2 + st) * NT + cl];
+        p.stats[((size_t)pending_tile * 2 + st) * p.cout + pending_nbi * NT + cl] = s;
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+struct V2Plan { bool ok; int nt; bool wres; int grid; int per_wg; int nitems; int nblk; int stat_rows; };
+
+static bool v2_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("OCT_DISABLE_V2"); on = (e && e[0] == '1') ? 0 : 1; }
+  return on == 1;
+}
+
+static V2Plan plan_v2(const OctConvDesc* d) {
+  V2Plan pl = {};
+  if (!v2_enabled()) return pl;
+  const int cin = d->c0 + d->c1;
+  pl.ok = d->dtype == OCT_DT_BF16 && d->taps == 9 && d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN &&
+          (d->w % 32) == 0 && (d->h % 8) == 0 && (d->c0 % 32) == 0 && (d->c1 % 32) == 0 && (d->cout % 32) == 0 &&
+          (d->split % 32) == 0;
+  if (!pl.ok) return pl;
+  pl.nt = d->cout == 32 ? 32 : (d->cout % 128 == 0 ? 128 : (d->cout % 64 == 0 ? 64 : 0));
+  if (pl.nt == 0) { pl.ok = false; return pl; }
+  pl.wres = (cin == 32) && (d->cout == pl.nt) && pl.nt <= 64;
+  pl.nblk = d->cout / pl.nt;
+  const int ntiles = (d->w / 32) * (d->h / 8) * d->n;
+  pl.nitems = ntiles * pl.nblk;
+  int target = 512;  // 2 workgroups per CU
+  if (target > pl.nitems) target = pl.nitems;
+  pl.per_wg = (pl.nitems + target - 1) / target;
+  pl.grid = (pl.nitems + pl.per_wg - 1) / pl.per_wg;
+  pl.stat_rows = pl.wres ? pl.grid : ntiles;
+  return pl;
+}
+
+int oct_conv_v2_stat_rows(const OctConvDesc* d) {
+  const V2Plan pl = plan_v2(d);
+  return pl.ok ? pl.stat_rows : -1;
+}
+
+template <int WM, int WN, int MF, int NF, bool WRES>
+static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
+  constexpr int TH = WM * MF;
+  constexpr int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4) * (int)sizeof(float);
+  if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(384), lds, s, p);
+  else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(384), lds, s, p);
+}
+
+// returns 1 when the launch was taken by this path, 0 when the shape is not eligible, <0 on error
+int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
+  const V2Plan pl = plan_v2(d);
+  if (!pl.ok) return 0;
+  Igemm2Params p;
+  p.x0 = (const bf16_t*)a->x0; p.x1 = (const bf16_t*)a->x1;
+  p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
+  p.wp = (const bf16_t*)a->wpacked; p.y0 = (bf16_t*)a->y0; p.y1 = (bf16_t*)a->y1;
+  p.stats = d->want_stats ? a->stat_partials : nullptr;
+  p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.cout = d->cout; p.split = d->split;
+  p.xf0 = d->xform0; p.xf1 = d->xform1;
+  p.tiles_x = d->w / 32; p.tiles_y = d->h / 8; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;
+  p.nch = (d->c0 + d->c1) / 32; p.nk16 = (d->c0 + d->c1) / 16;
+  hipStream_t s = as_stream(stream);
+  if (pl.nt == 32) {
+    if (pl.wres) launch_v2<4, 1, 2, 1, true>(p, pl.grid, s); else launch_v2<4, 1, 2, 1, false>(p, pl.grid, s);
+  } else if (pl.nt == 64) {
+    if (pl.wres) launch_v2<2, 2, 4, 1, true>(p, pl.grid, s); else launch_v2<2, 2, 4, 1, false>(p, pl.grid, s);
+  } else {
+    launch_v2<2, 2, 4, 2, false>(p, pl.grid, s);
+  }
+  int rc = oct_check_launch("igemm2");
+  return rc ? rc : 1;
+}

@@ -186,6 +186,10 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   OCT_CHECK(!(d->dy_mode == OCT_IN_S2D && (d->cout & 3)), "oct_conv_wgrad: S2D dy needs cout %% 4 == 0");
   OCT_CHECK(!(d->xform0 && (!a->scale0 || !a->shift0)), "oct_conv_wgrad: xform0 without scale/shift");
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
+  {
+    const int took = oct_conv_wgrad_v2(d, a, stream);
+    if (took != 0) return took < 0 ? took : OCT_OK;
+  }
   WgradParams p;
   p.x0 = a->x0; p.x1 = a->x1; p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
   p.dy = a->dy; p.dwp = a->dwp;

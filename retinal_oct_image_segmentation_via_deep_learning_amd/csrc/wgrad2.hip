@@ -1,0 +1,287 @@
+// Weight gradient, pipelined bf16 path for regular shapes (W % 32 == 0, H % 8 == 0, all channel
+// counts multiples of 32).  Same math as wgrad.hip:
+//
+//   dW[tap][co][ci] = sum over pixels  dY[p][co] * A[p + tap][ci]
+//
+// Round-1 profile: the generic kernel gathered every MFMA fragment with 8 scalar LDS reads and was
+// LDS-issue bound (26.8 of 77 ms per step).  Here
+//  * the contraction index (pixel) is brought onto the MFMA k axis with ds_read_b64_tr_b16: the LDS
+//    tiles keep the NHWC order they are staged in ([pixel][32 channels], 64-B rows, so four pixel
+//    rows of a transposed read cover all 64 banks exactly once) and the hardware transposes
+//    4 pixels x 16 channels per 16-lane group -- two reads per fragment instead of eight;
+//  * two producer waves stage dY (plain copy) and the input halo tile (BN+ReLU fused, virtual
+//    concat) two stages ahead of four MFMA waves, double-buffered LDS, one barrier per stage;
+//  * each MFMA wave keeps all 9 tap accumulators of one 32(co) x 32(ci) block (144 registers)
+//    across the whole persistent tile loop and issues its fp32 atomics once at the end.
+#include "common.h"
+#include <stdlib.h>
+
+struct Wgrad2Params {
+  const bf16_t* x0; const bf16_t* x1;
+  const float* sc0; const float* sh0; const float* sc1; const float* sh1;
+  const bf16_t* dy; float* dwp;
+  int n, h, w, c0, c1, ktot, cout, xf0, xf1, dy_mode;
+  int tiles_x, tiles_y, ntiles, per_wg;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned w2_pack(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (bf16_t)a;
+  v[1] = (bf16_t)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// one MFMA operand fragment (8 contraction pixels per lane) through two transposed LDS reads
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base_lo));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base_lo + 4 * 64));  // pixels +4
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TAPS, int CB, int IB, int TH>
+__global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
+  constexpr int TW = 32;
+  constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr int NPI = LH * LW, NPD = TH * TW;          // pixels of the input / dY tile
+  constexpr int INB = NPI * 64, DYB = NPD * 64;        // bytes per 32-channel block
+  constexpr int STAGEB = IB * INB + CB * DYB;
+  constexpr int SI = (NPI * 4 * IB + 127) / 128, SD = (NPD * 4 * CB + 127) / 128;
+  constexpr int PAIRS = CB * IB, PS = 4 / PAIRS, ROWS = TH / PS;
+  static_assert(PAIRS == 1 || PAIRS == 4, "1 or 4 channel-block pairs per workgroup");
+  typedef Mma<bf16_t> M;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co_sb = blockIdx.y * (32 * CB), ci_sb = blockIdx.z * (32 * IB);
+  const int t0 = blockIdx.x * p.per_wg, t1 = min(t0 + p.per_wg, p.ntiles);
+  if (t0 >= t1) return;
+  const int nstage = t1 - t0;
+
+  if (wave >= 4) {
+    // ============================== producer waves ==============================
+    const int ptid = tid - 256, g = ptid & 3, pb = ptid >> 2;
+    constexpr int SIB = (NPI * 4 + 127) / 128;   // input slots per 32-channel block
+    constexpr int SDB = (NPD * 4 + 127) / 128;   // dY slots per 32-row block
+    u32x4 RI[IB][SIB], RD[CB][SDB];
+    unsigned vmask[IB];
+    // per-slot constants (shared by all blocks): pixel offset from the tile origin + border code
+    int reli[SIB], reld[SDB];
+    unsigned code[SIB];
+#pragma unroll
+    for (int j = 0; j < SIB; ++j) {
+      const int pix = pb + 32 * j;
+      const int ly = pix / LW, lx = pix - ly * LW;
+      reli[j] = (ly - HALO) * p.w + (lx - HALO);
+      unsigned c = pix >= NPI ? 16u : 0u;
+      if (HALO) c |= (ly == 0 ? 1u : 0u) | (ly == LH - 1 ? 2u : 0u) | (lx == 0 ? 4u : 0u) | (lx == LW - 1 ? 8u : 0u);
+      code[j] = c;
+    }
+#pragma unroll
+    for (int j = 0; j < SDB; ++j) {
+      const int pix = pb + 32 * j;  // NPD is a multiple of 32: every dY slot is live
+      const int ly = pix / TW, lx = pix - ly * TW;
+      reld[j] = (p.dy_mode == OCT_IN_S2D) ? (2 * ly) * (2 * p.w) + 2 * lx : ly * p.w + lx;
+    }
+    auto issue = [&](int s) {
+      int t = t0 + s;
+      const int txi = t % p.tiles_x; t /= p.tiles_x;
+      const int tyi = t % p.tiles_y; const int img = t / p.tiles_y;
+      const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
+                            (txi == p.tiles_x - 1 ? 8u : 0u);
+      const size_t origin = ((size_t)img * p.h + tyi * TH) * p.w + txi * TW;
+#pragma unroll
+      for (int blk = 0; blk < IB; ++blk) {
+        const int cg = ci_sb + blk * 32;
+        const bool second = cg >= p.c0;
+        const int cs = second ? p.c1 : p.c0;
+        const bf16_t* base = (second ? p.x1 + origin * p.c1 + (cg - p.c0) : p.x0 + origin * p.c0 + cg) + g * 8;
+        unsigned vm = 0;
+#pragma unroll
+        for (int j = 0; j < SIB; ++j) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if ((code[j] & edge) == 0) {
+            v = *reinterpret_cast<const u32x4*>(base + __mul24(reli[j], cs));
+            vm |= 1u << j;
+          }
+          RI[blk][j] = v;
+        }
+        vmask[blk] = vm;
+      }
+#pragma unroll
+      for (int blk = 0; blk < CB; ++blk) {
+        const int row = co_sb + blk * 32;  // GEMM row = output channel (or (dydx, co) for the deconv)
+        const bf16_t* base;
+        int cs;
+        if (p.dy_mode == OCT_IN_S2D) {
+          cs = p.cout >> 2;
+          const int dydx = row / cs, co = row - dydx * cs;
+          const size_t o2 = ((size_t)img * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
+          base = p.dy + o2 * cs + co + g * 8;
+        } else {
+          cs = p.cout;
+          base = p.dy + origin * cs + row + g * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < SDB; ++j) RD[blk][j] = *reinterpret_cast<const u32x4*>(base + __mul24(reld[j], cs));
+      }
+    };
+    auto commit = [&](unsigned char* buf) {
+#pragma unroll
+      for (int blk = 0; blk < IB; ++blk) {
+        const int cg = ci_sb + blk * 32;
+        const bool second = cg >= p.c0;
+        const bool xf = second ? (p.xf1 != 0) : (p.xf0 != 0);
+        float s[8], b[8];
+        if (xf) {
+          const float* sc = (second ? p.sc1 + (cg - p.c0) : p.sc0 + cg) + g * 8;
+          const float* sh = (second ? p.sh1 + (cg - p.c0) : p.sh0 + cg) + g * 8;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh), b1 = *reinterpret_cast<const f32x4*>(sh + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s[j] = s0[j]; s[4 + j] = s1[j]; b[j] = b0[j]; b[4 + j] = b1[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < SIB; ++j) {
+          if ((code[j] & 16u) == 0) {
+            u32x4 v = RI[blk][j];
+            if (xf && ((vmask[blk] >> j) & 1u)) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float lo = fmaxf(fmaf(__uint_as_float(v[e] << 16), s[2 * e], b[2 * e]), 0.f);
+                const float hi = fmaxf(fmaf(__uint_as_float(v[e] & 0xffff0000u), s[2 * e + 1], b[2 * e + 1]), 0.f);
+                v[e] = w2_pack(lo, hi);
+              }
+            }
+            *reinterpret_cast<u32x4*>(buf + blk * INB + (pb + 32 * j) * 64 + g * 16) = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int blk = 0; blk < CB; ++blk)
+#pragma unroll
+        for (int j = 0; j < SDB; ++j)
+          *reinterpret_cast<u32x4*>(buf + IB * INB + blk * DYB + (pb + 32 * j) * 64 + g * 16) = RD[blk][j];
+    };
+    issue(0);
+    commit(smem);
+    if (nstage > 1) issue(1);
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < nstage; ++s) {
+      if (s + 1 < nstage) commit(smem + (cur ^ 1) * STAGEB);
+      if (s + 2 < nstage) issue(s + 2);
+      __syncthreads();
+      cur ^= 1;
+    }
+    return;
+  }
+
+  // ================================ MFMA waves ================================
+  const int pair = wave % PAIRS, psx = wave / PAIRS;
+  const int cb = pair / IB, ib = pair % IB;
+  const int g4 = lane >> 4, li = lane & 15;
+  // transposed-read lane address inside a [pixel][64 B] block: pixel 8*(g4>>1) + (li>>2), channel 16*(g4&1) + 4*(li&3)
+  const int lane_off = (8 * (g4 >> 1) + (li >> 2)) * 64 + (16 * (g4 & 1) + 4 * (li & 3)) * 2;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < nstage; ++s) {
+    const unsigned char* in_t = smem + cur * STAGEB + ib * INB + lane_off;
+    const unsigned char* dy_t = smem + cur * STAGEB + IB * INB + cb * DYB + lane_off;
+#pragma unroll 1
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int ry = psx * ROWS + rr;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int xs = half * 16;
+        const bf16x8 a = tr_frag(dy_t + (ry * TW + xs) * 64);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
+          const bf16x8 b = tr_frag(in_t + ((ry + ty) * LW + xs + tx) * 64);
+          M::mma(acc[t], a, b);
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // D[row = co][col = ci]
+  const int r = lane & 31, hh = lane >> 5;
+  const int ci = ci_sb + ib * 32 + r;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co_sb + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      atomicAdd(&p.dwp[((size_t)t * p.cout + co) * p.ktot + ci], acc[t][i]);
+    }
+}
+
+static bool w2_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("OCT_DISABLE_V2"); on = (e && e[0] == '1') ? 0 : 1; }
+  return on == 1;
+}
+
+template <int TAPS, int CB, int IB, int TH>
+static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
+  constexpr int halo = TAPS == 9 ? 1 : 0;
+  constexpr int stage = IB * (TH + 2 * halo) * (32 + 2 * halo) * 64 + CB * TH * 32 * 64;
+  constexpr int lds = 2 * stage;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<TAPS, CB, IB, TH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.ntiles = p.tiles_x * p.tiles_y * p.n;
+  const int gy = nco / CB, gz = nci / IB;
+  int gx = (2 * stage * 2 <= 160 * 1024 ? 512 : 256) / (gy * gz);  // 2 workgroups per CU when LDS allows
+  if (gx < 1) gx = 1;
+  if (gx > p.ntiles) gx = p.ntiles;
+  p.per_wg = (p.ntiles + gx - 1) / gx;
+  gx = (p.ntiles + p.per_wg - 1) / p.per_wg;
+  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH>), dim3(gx, gy, gz), dim3(384), lds, s, p);
+}
+
+// returns 1 when taken, 0 when the shape is not eligible, <0 on error
+int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
+  if (!w2_enabled()) return 0;
+  const int ktot = d->c0 + d->c1;
+  const bool ok = d->dtype == OCT_DT_BF16 && (d->w % 32) == 0 && (d->h % 8) == 0 && (d->c0 % 32) == 0 &&
+                  (d->c1 % 32) == 0 && (d->cout % 32) == 0 &&
+                  (d->dy_mode == OCT_IN_PLAIN || ((d->cout >> 2) % 32) == 0);
+  if (!ok) return 0;
+  Wgrad2Params p;
+  p.x0 = (const bf16_t*)a->x0; p.x1 = (const bf16_t*)a->x1;
+  p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
+  p.dy = (const bf16_t*)a->dy; p.dwp = a->dwp;
+  p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.ktot = ktot; p.cout = d->cout;
+  p.xf0 = d->xform0; p.xf1 = d->xform1; p.dy_mode = d->dy_mode;
+  const int nco = d->cout / 32, nci = ktot / 32;
+  const bool big = (nco % 2 == 0) && (nci % 2 == 0);
+  hipStream_t s = as_stream(stream);
+  if (d->taps == 9) {
+    if (big) launch_w2<9, 2, 2, 4>(p, nco, nci, s); else launch_w2<9, 1, 1, 8>(p, nco, nci, s);
+  } else {
+    if (big) launch_w2<1, 2, 2, 4>(p, nco, nci, s); else launch_w2<1, 1, 1, 8>(p, nco, nci, s);
+  }
+  int rc = oct_check_launch("wgrad2");
+  return rc ? rc : 1;
+}

@@ -68,6 +68,15 @@ CONV_SHAPES = [
     (1, 16, 16, 4, 4, 4),      # virtual concat, scalar path (tiny fixture shapes)
     (1, 2, 2, 32, 0, 64),      # bottleneck of the 32x32 fixtures
     (1, 16, 32, 3, 0, 8),      # in_channels = 3
+    # regular shapes -> pipelined bf16 kernel (igemm2.hip); fp32 stays on the generic kernel
+    (2, 16, 64, 32, 0, 32),    # weights resident, Cout 32
+    (1, 24, 32, 32, 0, 64),    # weights resident, Cout 64
+    (2, 8, 64, 64, 0, 32),     # two chunks, streamed weights
+    (1, 16, 32, 32, 32, 32),   # virtual concat (dec1conv1)
+    (1, 8, 32, 64, 64, 64),    # virtual concat, Cout 64
+    (1, 16, 32, 64, 0, 128),
+    (1, 8, 32, 128, 128, 256), # two channel blocks of 128, concat
+    (3, 8, 32, 96, 0, 192),    # Cout multiple of 64 only
 ]
 
 
@@ -106,7 +115,7 @@ def test_conv3x3_fprop_and_stats(env, dt, shape, xform):
     wd = fdev(wt)
     wp = eng._pack("w", wd, L.PACK_CONV_FPROP, cout, c0 + c1)
     y = torch.full((n, h, w, cout), float("nan"), dtype=tdt(dt), device="cuda")
-    nblk = eng._stat_blocks(cout, n, h, w)
+    nblk = eng._stat_blocks(cout, n, h, w, c0, c1)
     part = torch.full((nblk, 2, cout), float("nan"), dtype=torch.float32, device="cuda")
     eng._conv(src, wp, cout, 9, n, h, w, y, stats=part)
     torch.cuda.synchronize()
