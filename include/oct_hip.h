@@ -124,6 +124,7 @@ typedef struct OctWgradArgs {
   const float* scale1; const float* shift1;
   const void* dy;
   float* dwp;
+  float* dbias; /* optional: += sum over pixels of dy per real output channel (bias gradient); caller zeroes */
 } OctWgradArgs;
 int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
 /* dwp -> torch-layout gradient.  mode: OCT_PACK_CONV_FPROP (grad[co][ci][tap]),

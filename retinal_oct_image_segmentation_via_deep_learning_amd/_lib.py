@@ -42,7 +42,7 @@ class WgradDesc(C.Structure):
 
 
 class WgradArgs(C.Structure):
-    _fields_ = [(k, c_void_p) for k in ("x0", "x1", "scale0", "shift0", "scale1", "shift1", "dy", "dwp")]
+    _fields_ = [(k, c_void_p) for k in ("x0", "x1", "scale0", "shift0", "scale1", "shift1", "dy", "dwp", "dbias")]
 
 
 class HeadDesc(C.Structure):

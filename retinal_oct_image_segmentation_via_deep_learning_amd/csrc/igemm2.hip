@@ -21,8 +21,8 @@ struct Igemm2Params {
   const bf16_t* x0; const bf16_t* x1;
   const float* sc0; const float* sh0; const float* sc1; const float* sh1;
   const bf16_t* wp;
-  bf16_t* y0; bf16_t* y1; float* stats;
-  int n, h, w, c0, c1, cout, split, xf0, xf1;
+  bf16_t* y0; bf16_t* y1; float* stats; const float* bias;
+  int n, h, w, c0, c1, cout, split, xf0, xf1, in_mode, out_mode;
   int tiles_x, tiles_y, nblk, nitems, per_wg, nch, nk16;
 };
 
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
     for (int i = 0; i < NSLOT; ++i) {
       const int pix = pbase + 32 * i;
       const int ly = pix / LW, lx = pix - ly * LW;
-      relp[i] = (ly - HALO) * p.w + (lx - HALO);
+      relp[i] = (p.in_mode == OCT_IN_S2D) ? (2 * ly) * (2 * p.w) + 2 * lx : (ly - HALO) * p.w + (lx - HALO);
       unsigned c = pix >= NPIX ? 16u : 0u;
       if (HALO) c |= (ly == 0 ? 1u : 0u) | (ly == LH - 1 ? 2u : 0u) | (lx == 0 ? 4u : 0u) | (lx == LW - 1 ? 8u : 0u);
       code[i] = c;
@@ -90,9 +90,16 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
       const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
                             (txi == p.tiles_x - 1 ? 8u : 0u);
       const size_t origin = ((size_t)img * p.h + tyi * TH) * p.w + txi * TW;
-      const bool second = ch * 32 >= p.c0;  // uniform: every 32-channel chunk lies in one source
+      const bool second = p.in_mode == OCT_IN_PLAIN && ch * 32 >= p.c0;  // uniform: a 32-channel chunk lies in one source
       const int cs = second ? p.c1 : p.c0;
-      const bf16_t* base = (second ? p.x1 + origin * p.c1 + (ch * 32 - p.c0) : p.x0 + origin * p.c0 + ch * 32) + grp * 8;
+      const bf16_t* base;
+      if (p.in_mode == OCT_IN_S2D) {  // k = (dy*2+dx)*C + c of the 2H x 2W tensor
+        const int dydx = (ch * 32) / p.c0, cc = ch * 32 - dydx * p.c0;
+        const size_t o2 = ((size_t)img * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
+        base = p.x0 + o2 * p.c0 + cc + grp * 8;
+      } else {
+        base = (second ? p.x1 + origin * p.c1 + (ch * 32 - p.c0) : p.x0 + origin * p.c0 + ch * 32) + grp * 8;
+      }
       vmask = 0;
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
@@ -106,8 +113,9 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
     };
     auto commit = [&](int sidx, unsigned char* buf) {
       const int ch = sidx - (sidx / p.nch) * p.nch;
-      const int cg = ch * 32 + grp * 8;
-      const bool first = cg < p.c0;
+      int cg = ch * 32 + grp * 8;
+      if (p.in_mode == OCT_IN_S2D) cg -= ((ch * 32) / p.c0) * p.c0;
+      const bool first = p.in_mode == OCT_IN_S2D || cg < p.c0;
       const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
       float s[8], b[8];
       if (xf) {
@@ -245,19 +253,36 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
         const int cb0 = (nbi * (NT / 32) + wn * NF + q) * 32;
-        bf16_t* dst; int cd, co;
-        if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
+        bf16_t* dst; int cd, co, dydx = 0;
+        if (p.out_mode == OCT_OUT_D2S) {
+          cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0;
+        } else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
         else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
+        float bv[16];
+        if (p.out_mode == OCT_OUT_D2S && p.bias) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co + 8 * g + 4 * hh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[4 * g + j] = b4[j];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) bv[i] = 0.f;
+        }
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
-          const size_t pix = ((size_t)img * p.h + tyi * TH + wm * MF + m) * p.w + txi * TW + r;
+          const int oy = tyi * TH + wm * MF + m, ox = txi * TW + r;
+          const size_t pix = (p.out_mode == OCT_OUT_D2S)
+                                 ? ((size_t)img * (2 * p.h) + 2 * oy + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * ox + (dydx & 1)
+                                 : ((size_t)img * p.h + oy) * p.w + ox;
           bf16_t* row = dst + pix * cd + co;
 #pragma unroll
           for (int g = 0; g < 4; g += 2) {
-            unsigned lo0 = pack_bf16x2(acc[m][q][4 * g], acc[m][q][4 * g + 1]);
-            unsigned hi0 = pack_bf16x2(acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]);
-            unsigned lo1 = pack_bf16x2(acc[m][q][4 * g + 4], acc[m][q][4 * g + 5]);
-            unsigned hi1 = pack_bf16x2(acc[m][q][4 * g + 6], acc[m][q][4 * g + 7]);
+            unsigned lo0 = pack_bf16x2(acc[m][q][4 * g] + bv[4 * g], acc[m][q][4 * g + 1] + bv[4 * g + 1]);
+            unsigned hi0 = pack_bf16x2(acc[m][q][4 * g + 2] + bv[4 * g + 2], acc[m][q][4 * g + 3] + bv[4 * g + 3]);
+            unsigned lo1 = pack_bf16x2(acc[m][q][4 * g + 4] + bv[4 * g + 4], acc[m][q][4 * g + 5] + bv[4 * g + 5]);
+            unsigned hi1 = pack_bf16x2(acc[m][q][4 * g + 6] + bv[4 * g + 6], acc[m][q][4 * g + 7] + bv[4 * g + 7]);
             // lanes 32-63 of (lo0,hi0) <-> lanes 0-31 of (lo1,hi1): afterwards the lower half-wave holds
             // channels 8g..8g+7 and the upper half-wave 8g+8..8g+15 of its pixel, 16 contiguous bytes
             auto a = __builtin_amdgcn_permlane32_swap(lo0, lo1, false, false);
@@ -346,14 +371,17 @@ static bool v2_enabled() {
 static V2Plan plan_v2(const OctConvDesc* d) {
   V2Plan pl = {};
   if (!v2_enabled()) return pl;
-  const int cin = d->c0 + d->c1;
-  pl.ok = d->dtype == OCT_DT_BF16 && d->taps == 9 && d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN &&
-          (d->w % 32) == 0 && (d->h % 8) == 0 && (d->c0 % 32) == 0 && (d->c1 % 32) == 0 && (d->cout % 32) == 0 &&
-          (d->split % 32) == 0;
+  const int cin = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
+  pl.ok = d->dtype == OCT_DT_BF16 && (d->w % 32) == 0 && (d->h % 8) == 0 && (d->c0 % 32) == 0 &&
+          (d->c1 % 32) == 0 && (d->cout % 32) == 0 && (d->split % 32) == 0;
+  if (d->taps == 9) pl.ok = pl.ok && d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN;
+  else pl.ok = pl.ok && !d->want_stats && d->split == 0 &&
+               ((d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_D2S && ((d->cout >> 2) % 32) == 0) ||
+                (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN && d->c1 == 0));
   if (!pl.ok) return pl;
   pl.nt = d->cout == 32 ? 32 : (d->cout % 128 == 0 ? 128 : (d->cout % 64 == 0 ? 64 : 0));
   if (pl.nt == 0) { pl.ok = false; return pl; }
-  pl.wres = (cin == 32) && (d->cout == pl.nt) && pl.nt <= 64;
+  pl.wres = (d->taps == 9) && (cin == 32) && (d->cout == pl.nt) && pl.nt <= 64;
   pl.nblk = d->cout / pl.nt;
   const int ntiles = (d->w / 32) * (d->h / 8) * d->n;
   pl.nitems = ntiles * pl.nblk;
@@ -377,6 +405,12 @@ static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(384), lds, s, p);
   else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(384), lds, s, p);
 }
+template <int WM, int WN, int MF, int NF>
+static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
+  constexpr int TH = WM * MF;
+  constexpr int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4) * (int)sizeof(float);
+  hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(384), lds, s, p);
+}
 
 // returns 1 when the launch was taken by this path, 0 when the shape is not eligible, <0 on error
 int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
@@ -387,12 +421,18 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
   p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
   p.wp = (const bf16_t*)a->wpacked; p.y0 = (bf16_t*)a->y0; p.y1 = (bf16_t*)a->y1;
   p.stats = d->want_stats ? a->stat_partials : nullptr;
+  p.bias = a->bias; p.in_mode = d->in_mode; p.out_mode = d->out_mode;
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.cout = d->cout; p.split = d->split;
   p.xf0 = d->xform0; p.xf1 = d->xform1;
   p.tiles_x = d->w / 32; p.tiles_y = d->h / 8; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;
-  p.nch = (d->c0 + d->c1) / 32; p.nk16 = (d->c0 + d->c1) / 16;
+  const int ktot = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
+  p.nch = ktot / 32; p.nk16 = ktot / 16;
   hipStream_t s = as_stream(stream);
-  if (pl.nt == 32) {
+  if (d->taps == 1) {
+    if (pl.nt == 32) launch_v2_1x1<4, 1, 2, 1>(p, pl.grid, s);
+    else if (pl.nt == 64) launch_v2_1x1<2, 2, 4, 1>(p, pl.grid, s);
+    else launch_v2_1x1<2, 2, 4, 2>(p, pl.grid, s);
+  } else if (pl.nt == 32) {
     if (pl.wres) launch_v2<4, 1, 2, 1, true>(p, pl.grid, s); else launch_v2<4, 1, 2, 1, false>(p, pl.grid, s);
   } else if (pl.nt == 64) {
     if (pl.wres) launch_v2<2, 2, 4, 1, true>(p, pl.grid, s); else launch_v2<2, 2, 4, 1, false>(p, pl.grid, s);

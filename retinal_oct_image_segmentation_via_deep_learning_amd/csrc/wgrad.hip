@@ -14,7 +14,7 @@
 struct WgradParams {
   const void* x0; const void* x1;
   const float* sc0; const float* sh0; const float* sc1; const float* sh1;
-  const void* dy; float* dwp;
+  const void* dy; float* dwp; float* dbias;
   int n, h, w;
   int c0, c1, ktot;
   int cout;            // GEMM rows (4*Cout for the deconv)
@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;  // bias gradient: this lane's output channel (co0 + r), its share of the pixels
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     int bx = tile;
@@ -153,6 +154,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       Frag a = M::zero();
 #pragma unroll
       for (int j = 0; j < 8; ++j) M::set(a, j, dy_tile[(row * TW + xs + j) * PIXE + r]);
+      if (p.dbias && blockIdx.z == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += to_f32(dy_tile[(row * TW + xs + j) * PIXE + r]);
+      }
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
@@ -162,6 +167,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         M::mma(acc[t], a, b);
       }
     }
+  }
+  if (p.dbias && blockIdx.z == 0) {
+    bsum += __shfl_xor(bsum, 32);
+    const int cr = (p.dy_mode == OCT_IN_S2D) ? (p.cout >> 2) : p.cout;
+    if (hh == 0 && co0 + r < p.cout) atomicAdd(&p.dbias[(co0 + r) % cr], bsum);
   }
   // D[row = co][col = ci]: reg i -> co = co0 + (i&3) + 8*(i>>2) + 4*hh ; lane -> ci = ci0 + r
   const int ci = ci0 + r;
@@ -192,7 +202,7 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   }
   WgradParams p;
   p.x0 = a->x0; p.x1 = a->x1; p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
-  p.dy = a->dy; p.dwp = a->dwp;
+  p.dy = a->dy; p.dwp = a->dwp; p.dbias = a->dbias;
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.ktot = d->c0 + d->c1; p.cout = d->cout;
   p.xf0 = d->xform0; p.xf1 = d->xform1; p.dy_mode = d->dy_mode;
   p.tiles_x = ceil_div(d->w, 32); p.tiles_y = ceil_div(d->h, 8); p.ntiles = p.tiles_x * p.tiles_y * d->n;

@@ -19,7 +19,7 @@
 struct Wgrad2Params {
   const bf16_t* x0; const bf16_t* x1;
   const float* sc0; const float* sh0; const float* sc1; const float* sh1;
-  const bf16_t* dy; float* dwp;
+  const bf16_t* dy; float* dwp; float* dbias;
   int n, h, w, c0, c1, ktot, cout, xf0, xf1, dy_mode;
   int tiles_x, tiles_y, ntiles, per_wg;
 };
@@ -196,6 +196,14 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // bias gradient = sum over pixels of dY: one more MFMA per k-step against an all-ones operand
+  const bool do_bias = (p.dbias != nullptr) && (ib == 0) && (blockIdx.z == 0);
+  f32x16 accb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accb[i] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
 
   __syncthreads();
   int cur = 0;
@@ -209,6 +217,7 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
       for (int half = 0; half < 2; ++half) {
         const int xs = half * 16;
         const bf16x8 a = tr_frag(dy_t + (ry * TW + xs) * 64);
+        if (do_bias) M::mma(accb, a, ones);
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
           const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
@@ -231,6 +240,14 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
       const int co = co_sb + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
       atomicAdd(&p.dwp[((size_t)t * p.cout + co) * p.ktot + ci], acc[t][i]);
     }
+  if (do_bias && r == 0) {
+    const int cr = (p.dy_mode == OCT_IN_S2D) ? (p.cout >> 2) : p.cout;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co_sb + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      atomicAdd(&p.dbias[co % cr], accb[i]);
+    }
+  }
 }
 
 static bool w2_enabled() {
@@ -271,7 +288,7 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
   Wgrad2Params p;
   p.x0 = (const bf16_t*)a->x0; p.x1 = (const bf16_t*)a->x1;
   p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
-  p.dy = (const bf16_t*)a->dy; p.dwp = a->dwp;
+  p.dy = (const bf16_t*)a->dy; p.dwp = a->dwp; p.dbias = a->dbias;
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.ktot = ktot; p.cout = d->cout;
   p.xf0 = d->xform0; p.xf1 = d->xform1; p.dy_mode = d->dy_mode;
   const int nco = d->cout / 32, nci = ktot / 32;

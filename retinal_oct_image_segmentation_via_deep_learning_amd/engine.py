@@ -160,7 +160,7 @@ class UNetEngine:
         d = L.ConvDesc(self.dt, n, h, w, c0, c1, cout, 9, 0, 0, 0, 0, 0, 1)
         return L.lib().oct_conv_stat_blocks(C.byref(d))
 
-    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN):
+    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None):
         ktot = src.channels
         dwp = torch.zeros((taps, cout, ktot), dtype=torch.float32, device=dy.device)
         d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
@@ -169,7 +169,7 @@ class UNetEngine:
         a = L.WgradArgs(L.ptr(src.x0), L.ptr(src.x1),
                         L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                         L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
-                        L.ptr(dy), L.ptr(dwp))
+                        L.ptr(dy), L.ptr(dwp), L.ptr(dbias))
         ev = self._prof_begin()
         L.check(L.lib().oct_conv_wgrad(C.byref(d), C.byref(a), _stream()), "oct_conv_wgrad")
         self._prof_end(ev, "wgrad")
@@ -381,9 +381,11 @@ class UNetEngine:
             prev, u = ctx.ups[k]
             cin_d, cout_d = prev.cout, prev.cout // 2
             hl, wl = prev.h, prev.w
-            L.check(lib.oct_channel_sum(self.dt, du.data_ptr(), G[f"upconv{k}.bias"].data_ptr(),
-                                        n * 4 * hl * wl, cout_d, int(accumulate), _stream()), "oct_channel_sum")
-            dwp = self._wgrad(Src(prev.y, cin_d, prev.bn), du, 4 * cout_d, 1, n, hl, wl, dy_mode=L.IN_S2D)
+            bgrad = G[f"upconv{k}.bias"]
+            if not accumulate:
+                bgrad.zero_()
+            dwp = self._wgrad(Src(prev.y, cin_d, prev.bn), du, 4 * cout_d, 1, n, hl, wl, dy_mode=L.IN_S2D,
+                              dbias=bgrad)
             self._unpack(L.PACK_DECONV_FPROP, dwp, G[f"upconv{k}.weight"], cout_d, cin_d, accumulate)
             wkey = f"upconv{k}.weight"
             wp = self._pack(wkey, P[wkey], L.PACK_DECONV_DGRAD, cout_d, cin_d)

@@ -164,7 +164,8 @@ def test_conv3x3_wgrad(env, dt, shape):
     close(grad.cpu().numpy(), dw, dt, "wgrad", scale_tol=3e-5 if dt == "f32" else 4e-3)
 
 
-DECONV_SHAPES = [(2, 4, 8, 16, 8), (1, 8, 16, 64, 32), (1, 2, 2, 64, 32), (1, 4, 4, 8, 4), (1, 8, 32, 128, 64)]
+DECONV_SHAPES = [(2, 4, 8, 16, 8), (1, 8, 16, 64, 32), (1, 2, 2, 64, 32), (1, 4, 4, 8, 4), (1, 8, 32, 128, 64),
+                 (2, 16, 32, 64, 32), (1, 8, 64, 256, 128), (1, 8, 32, 512, 256)]  # last three: pipelined bf16 path
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -189,17 +190,19 @@ def test_deconv2x2_fwd_dgrad_wgrad(env, dt, shape):
     da = torch.full((n, h, w, cin), float("nan"), dtype=tdt(dt), device="cuda")
     eng._conv(E.Src(dud, cout), eng._pack("u", wd, L.PACK_DECONV_DGRAD, cout, cin), cin, 1, n, h, w, da,
               in_mode=L.IN_S2D)
-    dwp = eng._wgrad(src, dud, 4 * cout, 1, n, h, w, dy_mode=L.IN_S2D)
+    db = torch.zeros((cout,), dtype=torch.float32, device="cuda")
+    dwp = eng._wgrad(src, dud, 4 * cout, 1, n, h, w, dy_mode=L.IN_S2D, dbias=db)  # bias grad fused into wgrad
     grad = torch.full((cin, cout, 2, 2), float("nan"), dtype=torch.float32, device="cuda")
     eng._unpack(L.PACK_DECONV_FPROP, dwp, grad, cout, cin, False)
-    db = torch.full((cout,), float("nan"), dtype=torch.float32, device="cuda")
-    L.check(L.lib().oct_channel_sum(eng.dt, dud.data_ptr(), db.data_ptr(), n * 4 * h * w, cout, 0,
+    db2 = torch.full((cout,), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(L.lib().oct_channel_sum(eng.dt, dud.data_ptr(), db2.data_ptr(), n * 4 * h * w, cout, 0,
                                     torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     rda, rdw, rdb = O.deconv2x2_bwd(eff.astype(np.float64), wq, du.astype(np.float64))
     close(host(da), rda, dt, "deconv dgrad")
     close(grad.cpu().numpy(), rdw, dt, "deconv wgrad", scale_tol=3e-5 if dt == "f32" else 4e-3)
-    close(db.cpu().numpy(), rdb, dt, "deconv bias grad", scale_tol=1e-4)
+    close(db.cpu().numpy(), rdb, dt, "deconv bias grad (fused)", scale_tol=1e-4)
+    close(db2.cpu().numpy(), rdb, dt, "channel_sum", scale_tol=1e-4)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
