@@ -25,6 +25,10 @@ int oct_check_launch(const char* what);
 int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream);
 int oct_conv_v2_stat_rows(const OctConvDesc* d);
 int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
+// first.hip: direct kernels for Conv2d(1 -> F)
+int oct_first_stat_rows(const OctConvDesc* d);
+int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream);
+int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }

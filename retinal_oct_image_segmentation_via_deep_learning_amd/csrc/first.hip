@@ -1,0 +1,171 @@
+// First layer of the U-Net (Conv2d(1 -> F, 3x3), YNet_2022.py:578 with in_channels = 1): K = 9 is
+// far too shallow for MFMA -- this is a bandwidth stencil.  Direct VALU kernels:
+//   fprop : one thread per pixel, 9 taps x F outputs from scalar-cached weights, 64-B NHWC store,
+//           BatchNorm partial sums kept in registers over a grid-stride loop;
+//   wgrad : one thread per (pixel, 8-channel group), 72 register accumulators, one LDS + atomic
+//           reduction per workgroup.
+// bf16 only; other dtypes / channel counts use the generic implicit-GEMM kernels.
+#include "common.h"
+#include <stdlib.h>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned f1_pack(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (bf16_t)a;
+  v[1] = (bf16_t)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) first_fprop_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                          bf16_t* __restrict__ y, float* __restrict__ stats, int n,
+                                                          int h, int w) {
+  // wp: the MFMA fragment-order packing of the (F,1,3,3) filter (OCT_PACK_CONV_FPROP, nk16 = 1):
+  // A[row = co][k = 0] sits at ((co/32 * 9 + tap) * 512 + (co%32) * 8)
+  __shared__ float sw[9 * F];
+  __shared__ float red[4][2][F];
+  for (int i = threadIdx.x; i < 9 * F; i += 256) {
+    const int co = i % F, tap = i / F;
+    sw[i] = (float)wp[((co >> 5) * 9 + tap) * 512 + (co & 31) * 8];
+  }
+  __syncthreads();
+  float s1[F], s2[F];
+#pragma unroll
+  for (int c = 0; c < F; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  const size_t npix = (size_t)n * h * w;
+  for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * 256) {
+    const int xx = pix % w;
+    const int yy = (pix / w) % h;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = (yy + dy >= 0) && (yy + dy < h) && (xx + dx >= 0) && (xx + dx < w);
+      v[t] = ok ? (float)x[pix + (ptrdiff_t)dy * w + dx] : 0.f;
+    }
+    float acc[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < F; ++c) acc[c] = fmaf(sw[t * F + c], v[t], acc[c]);
+#pragma unroll
+    for (int c = 0; c < F; c += 8) {
+      const u32x4 o = {f1_pack(acc[c], acc[c + 1]), f1_pack(acc[c + 2], acc[c + 3]), f1_pack(acc[c + 4], acc[c + 5]),
+                       f1_pack(acc[c + 6], acc[c + 7])};
+      *reinterpret_cast<u32x4*>(y + pix * F + c) = o;
+    }
+    if (stats) {
+#pragma unroll
+      for (int c = 0; c < F; ++c) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
+    }
+  }
+  if (stats) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+      const float a = wave_sum(s1[c]), b = wave_sum(s2[c]);
+      if (lane == 0) { red[wave][0][c] = a; red[wave][1][c] = b; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * F; i += 256) {
+      const int st = i / F, c = i % F;
+      stats[((size_t)blockIdx.x * 2 + st) * F + c] = red[0][st][c] + red[1][st][c] + red[2][st][c] + red[3][st][c];
+    }
+  }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          float* __restrict__ dwp, int n, int h, int w) {
+  constexpr int G = F / 8;
+  __shared__ float sacc[9 * F];
+  for (int i = threadIdx.x; i < 9 * F; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  const size_t npix = (size_t)n * h * w, total = npix * G;
+  const int g = threadIdx.x % G;  // 256 % G == 0: the channel group of a thread is loop invariant
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t pix = i / G;
+    const int xx = pix % w;
+    const int yy = (pix / w) % h;
+    const u32x4 d = *reinterpret_cast<const u32x4*>(dy + pix * F + g * 8);
+    float dv[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dv[2 * j] = __uint_as_float(d[j] << 16); dv[2 * j + 1] = __uint_as_float(d[j] & 0xffff0000u); }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ddy = t / 3 - 1, ddx = t % 3 - 1;
+      const bool ok = (yy + ddy >= 0) && (yy + ddy < h) && (xx + ddx >= 0) && (xx + ddx < w);
+      const float xv = ok ? (float)x[pix + (ptrdiff_t)ddy * w + ddx] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(dv[j], xv, acc[t][j]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // threads with equal g across the wave: reduce with shuffles over the lanes sharing g first
+      float v = acc[t][j];
+#pragma unroll
+      for (int o = 32; o >= G; o >>= 1) v += __shfl_xor(v, o);
+      if ((threadIdx.x & 63) < G) atomicAdd(&sacc[t * F + g * 8 + j], v);
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * F; i += 256) atomicAdd(&dwp[i], sacc[i]);  // dwp[tap][co][ci = 0]
+}
+
+static bool f1_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("OCT_DISABLE_V2"); on = (e && e[0] == '1') ? 0 : 1; }
+  return on == 1;
+}
+static bool first_ok(int dtype, int c0, int c1, int cout, int taps) {
+  return f1_enabled() && dtype == OCT_DT_BF16 && c0 == 1 && c1 == 0 && taps == 9 && (cout == 16 || cout == 32 || cout == 64);
+}
+static int first_grid(const OctConvDesc* d) {
+  const size_t npix = (size_t)d->n * d->h * d->w;
+  size_t b = (npix + 255) / 256;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+int oct_first_stat_rows(const OctConvDesc* d) {
+  if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->in_mode || d->out_mode || d->xform0 || d->split) return -1;
+  return first_grid(d);
+}
+
+int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
+  if (oct_first_stat_rows(d) < 0) return 0;
+  const int grid = first_grid(d);
+  hipStream_t s = as_stream(stream);
+  float* st = d->want_stats ? a->stat_partials : nullptr;
+#define LAUNCH(F) hipLaunchKernelGGL(first_fprop_kernel<F>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a->x0, \
+                                     (const bf16_t*)a->wpacked,                                      (bf16_t*)a->y0, st, d->n, d->h, d->w)
+  if (d->cout == 16) LAUNCH(16); else if (d->cout == 32) LAUNCH(32); else LAUNCH(64);
+#undef LAUNCH
+  int rc = oct_check_launch("first_fprop");
+  return rc ? rc : 1;
+}
+
+int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
+  if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
+  const size_t total = (size_t)d->n * d->h * d->w * (d->cout / 8);
+  size_t b = (total + 255) / 256;
+  if (b > 2048) b = 2048;
+  hipStream_t s = as_stream(stream);
+#define LAUNCH(F) hipLaunchKernelGGL(first_wgrad_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
+                                     (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w)
+  if (d->cout == 16) LAUNCH(16); else if (d->cout == 32) LAUNCH(32); else LAUNCH(64);
+#undef LAUNCH
+  int rc = oct_check_launch("first_wgrad");
+  return rc ? rc : 1;
+}

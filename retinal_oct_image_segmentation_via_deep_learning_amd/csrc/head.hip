@@ -142,10 +142,16 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_fwd_kernel(const HeadParams
 __global__ void head_loss_finalize_kernel(const double* __restrict__ partials, int nblocks, int classes, double npix,
                                           float w_ce, float w_dice, float eps, float* loss_out, float* dice_coef) {
   __shared__ double tot[OCT_HEAD_LOSS_SLOTS];
-  for (int i = threadIdx.x; i < OCT_HEAD_LOSS_SLOTS; i += blockDim.x) {
+  __shared__ double part[4][64];
+  {
+    // 256 threads: slot = tid % 64, quarter of the block range = tid / 64
+    const int slot = threadIdx.x & 63, qd = threadIdx.x >> 6;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * OCT_HEAD_LOSS_SLOTS + i];
-    tot[i] = s;
+    if (slot < OCT_HEAD_LOSS_SLOTS)
+      for (int b = qd; b < nblocks; b += 4) s += partials[(size_t)b * OCT_HEAD_LOSS_SLOTS + slot];
+    part[qd][slot] = s;
+    __syncthreads();
+    if (threadIdx.x < OCT_HEAD_LOSS_SLOTS) tot[threadIdx.x] = part[0][slot] + part[1][slot] + part[2][slot] + part[3][slot];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -266,7 +272,7 @@ extern "C" int oct_head_loss_finalize(const OctHeadDesc* d, const double* loss_p
   int rc = head_check(d, "oct_head_loss_finalize");
   if (rc) return rc;
   OCT_CHECK(loss_partials && loss_out && dice_coef && nblocks > 0, "oct_head_loss_finalize: bad args");
-  hipLaunchKernelGGL(head_loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), loss_partials, nblocks,
+  hipLaunchKernelGGL(head_loss_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), loss_partials, nblocks,
                      d->classes, (double)d->n * d->h * d->w, w_ce, w_dice, dice_eps, loss_out, dice_coef);
   return oct_check_launch("head_loss_finalize");
 }

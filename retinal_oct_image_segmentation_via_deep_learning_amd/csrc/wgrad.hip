@@ -197,7 +197,8 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   OCT_CHECK(!(d->xform0 && (!a->scale0 || !a->shift0)), "oct_conv_wgrad: xform0 without scale/shift");
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
   {
-    const int took = oct_conv_wgrad_v2(d, a, stream);
+    int took = oct_first_wgrad(d, a, stream);
+    if (took == 0) took = oct_conv_wgrad_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
   }
   WgradParams p;

@@ -156,8 +156,11 @@ class UNetEngine:
         L.check(L.lib().oct_conv_forward(C.byref(d), C.byref(a), _stream()), "oct_conv_forward")
         self._prof_end(ev, "igemm")
 
-    def _stat_blocks(self, cout, n, h, w, c0=1, c1=0):
-        d = L.ConvDesc(self.dt, n, h, w, c0, c1, cout, 9, 0, 0, 0, 0, 0, 1)
+    def _stat_blocks(self, cout, n, h, w, src: Src):
+        """rows of the partial-statistics buffer the conv with this exact descriptor will write"""
+        d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, 9,
+                       L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
+                       L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, 0, 0, 0, 1)
         return L.lib().oct_conv_stat_blocks(C.byref(d))
 
     def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None):
@@ -190,7 +193,7 @@ class UNetEngine:
         scale = torch.empty(cout, dtype=torch.float32, device=dev)
         shift = torch.empty_like(scale)
         if train:
-            nblk = self._stat_blocks(cout, n, h, w, src.c0, src.c1)
+            nblk = self._stat_blocks(cout, n, h, w, src)
             partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
             self._conv(src, wp, cout, 9, n, h, w, y, stats=partials)
             mean = torch.empty_like(scale)

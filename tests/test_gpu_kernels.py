@@ -77,6 +77,8 @@ CONV_SHAPES = [
     (1, 16, 32, 64, 0, 128),
     (1, 8, 32, 128, 128, 256), # two channel blocks of 128, concat
     (3, 8, 32, 96, 0, 192),    # Cout multiple of 64 only
+    (2, 16, 64, 1, 0, 32),     # first layer, in_channels = 1: direct stencil kernels (bf16)
+    (1, 24, 40, 1, 0, 16),
 ]
 
 
@@ -115,7 +117,7 @@ def test_conv3x3_fprop_and_stats(env, dt, shape, xform):
     wd = fdev(wt)
     wp = eng._pack("w", wd, L.PACK_CONV_FPROP, cout, c0 + c1)
     y = torch.full((n, h, w, cout), float("nan"), dtype=tdt(dt), device="cuda")
-    nblk = eng._stat_blocks(cout, n, h, w, c0, c1)
+    nblk = eng._stat_blocks(cout, n, h, w, src)
     part = torch.full((nblk, 2, cout), float("nan"), dtype=torch.float32, device="cuda")
     eng._conv(src, wp, cout, 9, n, h, w, y, stats=part)
     torch.cuda.synchronize()
