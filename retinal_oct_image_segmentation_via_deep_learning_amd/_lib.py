@@ -11,7 +11,7 @@ import subprocess
 import threading
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "liboct_hip.so")
+LIB_PATH = os.environ.get("OCT_HIP_LIB") or os.path.join(PKG_DIR, "liboct_hip.so")  # override: ablation builds
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 DT_BF16, DT_F32 = 0, 1

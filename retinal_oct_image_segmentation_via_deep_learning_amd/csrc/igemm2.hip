@@ -39,7 +39,7 @@ __device__ __forceinline__ float bf16lo(unsigned u) { return __uint_as_float(u <
 __device__ __forceinline__ float bf16hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS>
-__global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
+__global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   static_assert(WM * WN == 4, "four MFMA waves");
   constexpr int TH = WM * MF, TW = 32;
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
   constexpr int NPIX = LH * LW;
   constexpr int PIXB = 80;                      // 32 bf16 + 16 B pad: conflict-free ds_read_b128
   constexpr int BUFB = NPIX * PIXB;
-  constexpr int NSLOT = (NPIX + 31) / 32;       // producer: 32 pixels x 4 channel groups per pass
+  constexpr int NSLOT = (NPIX + 63) / 64;       // producers (4 waves): 64 pixels x 4 channel groups per pass
   constexpr int NT = WN * NF * 32;
   constexpr int KSTEPS = TAPS * 2;              // k16 steps per 32-channel chunk
   typedef Mma<bf16_t> M;
@@ -63,26 +63,42 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
   if (it0 >= it1) return;
   const int nstage = (it1 - it0) * p.nch;
 
+  // BN scale/shift of every input channel live in LDS: reading them with ds_read keeps them off the
+  // vmcnt queue (a global load issued at commit time would be YOUNGER than the prefetched stages and
+  // waiting for it would drain the whole ring -- vmcnt retires in order)
+  float* const sxf = reinterpret_cast<float*>(smem + 2 * BUFB) + (2 * WM * 2 * NT + 4);
+  {
+    const int kx = (p.in_mode == OCT_IN_S2D) ? p.c0 : p.c0 + p.c1;
+    for (int i = tid; i < kx; i += 512) {
+      const bool first = i < p.c0;
+      const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
+      sxf[i] = xf ? (first ? p.sc0[i] : p.sc1[i - p.c0]) : 1.f;
+      sxf[kx + i] = xf ? (first ? p.sh0[i] : p.sh1[i - p.c0]) : 0.f;
+    }
+  }
+  __syncthreads();
+
   if (wave >= 4) {
-    // =============================== producer waves (2) ===============================
+    // =============================== producer waves (4) ===============================
     // global -> registers (issued two stages ahead) -> BN+ReLU -> LDS halo tile of the next stage
     const int ptid = tid - 256, grp = ptid & 3, pbase = ptid >> 2;
-    u32x4 R[NSLOT];
-    unsigned vmask = 0;
+    constexpr int D = 4;            // stages of global loads in flight per producer thread
+    u32x4 R[D][NSLOT];
+    unsigned vmask[D];
     // per-slot constants: pixel offset relative to the tile origin and a border code
     // (bit0 top halo row, bit1 bottom, bit2 left, bit3 right, bit4 slot beyond the tile)
     int relp[NSLOT];
     unsigned code[NSLOT];
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
-      const int pix = pbase + 32 * i;
+      const int pix = pbase + 64 * i;
       const int ly = pix / LW, lx = pix - ly * LW;
       relp[i] = (p.in_mode == OCT_IN_S2D) ? (2 * ly) * (2 * p.w) + 2 * lx : (ly - HALO) * p.w + (lx - HALO);
       unsigned c = pix >= NPIX ? 16u : 0u;
       if (HALO) c |= (ly == 0 ? 1u : 0u) | (ly == LH - 1 ? 2u : 0u) | (lx == 0 ? 4u : 0u) | (lx == LW - 1 ? 8u : 0u);
       code[i] = c;
     }
-    auto issue = [&](int sidx) {
+    auto issue = [&](int sidx, u32x4 (&Rr)[NSLOT], unsigned& vm) {
       const int item = it0 + sidx / p.nch, ch = sidx - (sidx / p.nch) * p.nch;
       int t = item / p.nblk;
       const int txi = t % p.tiles_x; t /= p.tiles_x;
@@ -100,18 +116,18 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
       } else {
         base = (second ? p.x1 + origin * p.c1 + (ch * 32 - p.c0) : p.x0 + origin * p.c0 + ch * 32) + grp * 8;
       }
-      vmask = 0;
+      // Loads are UNCONDITIONAL (out-of-image / dead slots re-read the tile origin and are zeroed at
+      // commit): a load under a divergent branch makes hipcc fall back to s_waitcnt vmcnt(0) at every
+      // use, which drains the whole multi-stage prefetch ring.
+      vm = 0;
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if ((code[i] & edge) == 0) {
-          v = *reinterpret_cast<const u32x4*>(base + __mul24(relp[i], cs));
-          vmask |= 1u << i;
-        }
-        R[i] = v;
+        const bool ok = (code[i] & edge) == 0;
+        Rr[i] = *reinterpret_cast<const u32x4*>(base + (ok ? __mul24(relp[i], cs) : 0));
+        vm |= ok ? (1u << i) : 0u;
       }
     };
-    auto commit = [&](int sidx, unsigned char* buf) {
+    auto commit = [&](int sidx, unsigned char* buf, const u32x4 (&Rr)[NSLOT], unsigned vm) {
       const int ch = sidx - (sidx / p.nch) * p.nch;
       int cg = ch * 32 + grp * 8;
       if (p.in_mode == OCT_IN_S2D) cg -= ((ch * 32) / p.c0) * p.c0;
@@ -119,40 +135,52 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
       const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
       float s[8], b[8];
       if (xf) {
-        const float* sc = first ? p.sc0 + cg : p.sc1 + (cg - p.c0);
-        const float* sh = first ? p.sh0 + cg : p.sh1 + (cg - p.c0);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh), b1 = *reinterpret_cast<const f32x4*>(sh + 4);
+        const int kx = (p.in_mode == OCT_IN_S2D) ? p.c0 : p.c0 + p.c1;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sxf + cg), s1 = *reinterpret_cast<const f32x4*>(sxf + cg + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sxf + kx + cg), b1 = *reinterpret_cast<const f32x4*>(sxf + kx + cg + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s[j] = s0[j]; s[4 + j] = s1[j]; b[j] = b0[j]; b[4 + j] = b1[j]; }
       }
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
-        const int pix = pbase + 32 * i;
+        const int pix = pbase + 64 * i;
         if (pix < NPIX) {
-          u32x4 v = R[i];
-          if (xf && (vmask & (1u << i))) {
+          u32x4 v = Rr[i];
+          if (xf) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float lo = fmaxf(fmaf(bf16lo(v[j]), s[2 * j], b[2 * j]), 0.f);
               const float hi = fmaxf(fmaf(bf16hi(v[j]), s[2 * j + 1], b[2 * j + 1]), 0.f);
               v[j] = pack_bf16x2(lo, hi);
             }
-          }  // out-of-image pixels stay exactly zero (padding applies to the activated tensor)
+          }
+          // out-of-image pixels are exactly zero (padding applies to the activated tensor)
+          const bool live = (vm & (1u << i)) != 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = live ? v[j] : 0u;
           *reinterpret_cast<u32x4*>(buf + pix * PIXB + grp * 16) = v;
         }
       }
     };
-    issue(0);
-    commit(0, buf0);
-    if (nstage > 1) issue(1);
+    const int last = nstage - 1;
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(min(j, last), R[j], vmask[j]);   // stages past the end re-read the last one
+    commit(0, buf0, R[0], vmask[0]);
+    issue(min(D, last), R[0], vmask[0]);
     __syncthreads();
-    int cur = 0;
-    for (int s = 0; s < nstage; ++s) {
-      if (s + 1 < nstage) commit(s + 1, buf0 + (cur ^ 1) * BUFB);
-      if (s + 2 < nstage) issue(s + 2);
-      __syncthreads();
-      cur ^= 1;
+    // stage k lives in ring slot k % D; while the MFMA waves work on stage cs, stage cs+1 is written to
+    // the other LDS buffer and its slot is refilled with the loads of stage cs+1+D
+    for (int s0 = 0; s0 < nstage; s0 += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int cs = s0 + j;
+        if (cs < nstage) {
+          const int nx = cs + 1;
+          if (nx < nstage) commit(nx, buf0 + (nx & 1) * BUFB, R[(j + 1) % D], vmask[(j + 1) % D]);
+          issue(min(nx + D, last), R[(j + 1) % D], vmask[(j + 1) % D]);
+          __syncthreads();
+        }
+      }
     }
     if (STATS && WRES) __syncthreads();  // matches the barrier of the final statistics reduction
     return;
@@ -174,6 +202,9 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
       }
   }
 
+  constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? 3 : ((MF * NF >= 4) ? 6 : 9));
+  static_assert(KSTEPS % PF == 0, "ring slots must line up across stages");
+  Frag wring[WRES ? 1 : PF][NF];
   f32x16 acc[MF][NF];
   float s1[STATS ? NF : 1][16], s2[STATS ? NF : 1][16];  // BN partial sums (lane = pixel column)
   if (STATS) {
@@ -211,37 +242,52 @@ __global__ void __launch_bounds__(384) igemm2_kernel(const Igemm2Params p) {
     }
 
     // ---- MFMA phase over the staged 32-channel chunk ----
+    // Streamed weights ride a ring of PF fragments-steps that stays PF steps (>= ~700 cycles of MFMA
+    // work) ahead of the consumer, across stage boundaries, so an L2 round trip never stalls a step.
     {
       const unsigned char* tb = buf0 + cur * BUFB;
-      const int nb0 = nbi * (NT / 32) + wn * NF;
-      const bf16_t* wbase = p.wp + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512 + lane * 8;
+      const bf16_t* wbase = nullptr; const bf16_t* wbase_n = nullptr;
       const size_t qstride = (size_t)TAPS * p.nk16 * 512, tstride = (size_t)p.nk16 * 512;
-      Frag wcur[NF], wnxt[NF];
       if (!WRES) {
+        const int nb0 = nbi * (NT / 32) + wn * NF;
+        wbase = p.wp + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512 + lane * 8;
+        int n_ch = ch + 1, n_item = item;
+        if (n_ch == p.nch) { n_ch = 0; n_item = item + 1; }
+        if (n_item >= it1) { n_item = item; n_ch = ch; }  // last stage: harmless re-read of valid memory
+        const int n_tile = n_item / p.nblk, n_nbi = n_item - n_tile * p.nblk;
+        wbase_n = p.wp + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512 + lane * 8;
+        if (sidx == 0) {
 #pragma unroll
-        for (int q = 0; q < NF; ++q) wcur[q] = M::load(wbase + q * qstride);
+          for (int j = 0; j < PF; ++j)
+#pragma unroll
+            for (int q = 0; q < NF; ++q) wring[j][q] = M::load(wbase + q * qstride + (j >> 1) * tstride + (j & 1) * 512);
+        }
       }
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
         const int tap = s >> 1, k16 = s & 1;
         const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
-        if (!WRES && s + 1 < KSTEPS) {
-          const int tap2 = (s + 1) >> 1, k2 = (s + 1) & 1;
-#pragma unroll
-          for (int q = 0; q < NF; ++q) wnxt[q] = M::load(wbase + q * qstride + tap2 * tstride + k2 * 512);
-        }
         Frag xf[MF];
+#ifdef ABL_NO_XLOAD
+        if (s == 0)
+#endif
 #pragma unroll
         for (int m = 0; m < MF; ++m)
           xf[m] = M::load(tb + ((wm * MF + m + ty) * LW + (r + tx)) * PIXB + (k16 * 16 + 8 * hh) * 2);
 #pragma unroll
         for (int m = 0; m < MF; ++m)
 #pragma unroll
-          for (int q = 0; q < NF; ++q) M::mma(acc[m][q], WRES ? wres[s][q] : wcur[q], xf[m]);
+          for (int q = 0; q < NF; ++q) M::mma(acc[m][q], WRES ? wres[s][q] : wring[s % PF][q], xf[m]);
+#ifndef ABL_NO_WLOAD
         if (!WRES) {
+          const int s2 = s + PF;  // refill the slot just consumed
+          const bf16_t* wb = s2 < KSTEPS ? wbase : wbase_n;
+          const int s3 = s2 < KSTEPS ? s2 : s2 - KSTEPS;
 #pragma unroll
-          for (int q = 0; q < NF; ++q) wcur[q] = wnxt[q];
+          for (int q = 0; q < NF; ++q)
+            wring[s % PF][q] = M::load(wb + q * qstride + (s3 >> 1) * tstride + (s3 & 1) * 512);
         }
+#endif
       }
     }
 
@@ -401,15 +447,15 @@ int oct_conv_v2_stat_rows(const OctConvDesc* d) {
 template <int WM, int WN, int MF, int NF, bool WRES>
 static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  constexpr int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4) * (int)sizeof(float);
-  if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(384), lds, s, p);
-  else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(384), lds, s, p);
+  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * (p.c0 + p.c1)) * (int)sizeof(float);
+  if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(512), lds, s, p);
 }
 template <int WM, int WN, int MF, int NF>
 static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  constexpr int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4) * (int)sizeof(float);
-  hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(384), lds, s, p);
+  const int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * (p.c0 + p.c1)) * (int)sizeof(float);
+  hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(512), lds, s, p);
 }
 
 // returns 1 when the launch was taken by this path, 0 when the shape is not eligible, <0 on error

@@ -46,14 +46,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo) {
 }
 
 template <int TAPS, int CB, int IB, int TH>
-__global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
+__global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   constexpr int TW = 32;
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr int NPI = LH * LW, NPD = TH * TW;          // pixels of the input / dY tile
   constexpr int INB = NPI * 64, DYB = NPD * 64;        // bytes per 32-channel block
   constexpr int STAGEB = IB * INB + CB * DYB;
-  constexpr int SI = (NPI * 4 * IB + 127) / 128, SD = (NPD * 4 * CB + 127) / 128;
   constexpr int PAIRS = CB * IB, PS = 4 / PAIRS, ROWS = TH / PS;
   static_assert(PAIRS == 1 || PAIRS == 4, "1 or 4 channel-block pairs per workgroup");
   typedef Mma<bf16_t> M;
@@ -65,19 +64,31 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
   if (t0 >= t1) return;
   const int nstage = t1 - t0;
 
+  // BN scale/shift of this workgroup's input channels in LDS (kept off the in-order vmcnt queue)
+  float* const sxf = reinterpret_cast<float*>(smem + 2 * STAGEB);   // [2][32*IB]
+  for (int i = tid; i < 32 * IB; i += 512) {
+    const int cg = ci_sb + i;
+    const bool second = cg >= p.c0;
+    const bool xf = second ? (p.xf1 != 0) : (p.xf0 != 0);
+    sxf[i] = xf ? (second ? p.sc1[cg - p.c0] : p.sc0[cg]) : 1.f;
+    sxf[32 * IB + i] = xf ? (second ? p.sh1[cg - p.c0] : p.sh0[cg]) : 0.f;
+  }
+  __syncthreads();
+
   if (wave >= 4) {
     // ============================== producer waves ==============================
     const int ptid = tid - 256, g = ptid & 3, pb = ptid >> 2;
-    constexpr int SIB = (NPI * 4 + 127) / 128;   // input slots per 32-channel block
-    constexpr int SDB = (NPD * 4 + 127) / 128;   // dY slots per 32-row block
-    u32x4 RI[IB][SIB], RD[CB][SDB];
-    unsigned vmask[IB];
+    constexpr int SIB = (NPI * 4 + 255) / 256;   // input slots per 32-channel block (256 producer threads)
+    constexpr int SDB = (NPD * 4 + 255) / 256;   // dY slots per 32-row block
+    constexpr int D = 4;            // stages of global loads in flight per producer thread
+    struct Stage { u32x4 ri[IB][SIB]; u32x4 rd[CB][SDB]; unsigned vm[IB]; };
+    Stage R[D];
     // per-slot constants (shared by all blocks): pixel offset from the tile origin + border code
     int reli[SIB], reld[SDB];
     unsigned code[SIB];
 #pragma unroll
     for (int j = 0; j < SIB; ++j) {
-      const int pix = pb + 32 * j;
+      const int pix = pb + 64 * j;
       const int ly = pix / LW, lx = pix - ly * LW;
       reli[j] = (ly - HALO) * p.w + (lx - HALO);
       unsigned c = pix >= NPI ? 16u : 0u;
@@ -86,11 +97,11 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
     }
 #pragma unroll
     for (int j = 0; j < SDB; ++j) {
-      const int pix = pb + 32 * j;  // NPD is a multiple of 32: every dY slot is live
+      const int pix = pb + 64 * j;  // NPD is a multiple of 64: every dY slot is live
       const int ly = pix / TW, lx = pix - ly * TW;
       reld[j] = (p.dy_mode == OCT_IN_S2D) ? (2 * ly) * (2 * p.w) + 2 * lx : ly * p.w + lx;
     }
-    auto issue = [&](int s) {
+    auto issue = [&](int s, Stage& S) {
       int t = t0 + s;
       const int txi = t % p.tiles_x; t /= p.tiles_x;
       const int tyi = t % p.tiles_y; const int img = t / p.tiles_y;
@@ -103,17 +114,15 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
         const bool second = cg >= p.c0;
         const int cs = second ? p.c1 : p.c0;
         const bf16_t* base = (second ? p.x1 + origin * p.c1 + (cg - p.c0) : p.x0 + origin * p.c0 + cg) + g * 8;
+        // unconditional loads (see igemm2.hip): invalid slots re-read the tile origin, zeroed at commit
         unsigned vm = 0;
 #pragma unroll
         for (int j = 0; j < SIB; ++j) {
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if ((code[j] & edge) == 0) {
-            v = *reinterpret_cast<const u32x4*>(base + __mul24(reli[j], cs));
-            vm |= 1u << j;
-          }
-          RI[blk][j] = v;
+          const bool ok = (code[j] & edge) == 0;
+          S.ri[blk][j] = *reinterpret_cast<const u32x4*>(base + (ok ? __mul24(reli[j], cs) : 0));
+          vm |= ok ? (1u << j) : 0u;
         }
-        vmask[blk] = vm;
+        S.vm[blk] = vm;
       }
 #pragma unroll
       for (int blk = 0; blk < CB; ++blk) {
@@ -130,10 +139,10 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
           base = p.dy + origin * cs + row + g * 8;
         }
 #pragma unroll
-        for (int j = 0; j < SDB; ++j) RD[blk][j] = *reinterpret_cast<const u32x4*>(base + __mul24(reld[j], cs));
+        for (int j = 0; j < SDB; ++j) S.rd[blk][j] = *reinterpret_cast<const u32x4*>(base + __mul24(reld[j], cs));
       }
     };
-    auto commit = [&](unsigned char* buf) {
+    auto commit = [&](unsigned char* buf, const Stage& S) {
 #pragma unroll
       for (int blk = 0; blk < IB; ++blk) {
         const int cg = ci_sb + blk * 32;
@@ -141,8 +150,8 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
         const bool xf = second ? (p.xf1 != 0) : (p.xf0 != 0);
         float s[8], b[8];
         if (xf) {
-          const float* sc = (second ? p.sc1 + (cg - p.c0) : p.sc0 + cg) + g * 8;
-          const float* sh = (second ? p.sh1 + (cg - p.c0) : p.sh0 + cg) + g * 8;
+          const float* sc = sxf + blk * 32 + g * 8;
+          const float* sh = sxf + 32 * IB + blk * 32 + g * 8;
           const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
           const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh), b1 = *reinterpret_cast<const f32x4*>(sh + 4);
 #pragma unroll
@@ -151,8 +160,8 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
 #pragma unroll
         for (int j = 0; j < SIB; ++j) {
           if ((code[j] & 16u) == 0) {
-            u32x4 v = RI[blk][j];
-            if (xf && ((vmask[blk] >> j) & 1u)) {
+            u32x4 v = S.ri[blk][j];
+            if (xf) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float lo = fmaxf(fmaf(__uint_as_float(v[e] << 16), s[2 * e], b[2 * e]), 0.f);
@@ -160,7 +169,10 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
                 v[e] = w2_pack(lo, hi);
               }
             }
-            *reinterpret_cast<u32x4*>(buf + blk * INB + (pb + 32 * j) * 64 + g * 16) = v;
+            const bool live = ((S.vm[blk] >> j) & 1u) != 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = live ? v[e] : 0u;
+            *reinterpret_cast<u32x4*>(buf + blk * INB + (pb + 64 * j) * 64 + g * 16) = v;
           }
         }
       }
@@ -168,18 +180,25 @@ __global__ void __launch_bounds__(384) wgrad2_kernel(const Wgrad2Params p) {
       for (int blk = 0; blk < CB; ++blk)
 #pragma unroll
         for (int j = 0; j < SDB; ++j)
-          *reinterpret_cast<u32x4*>(buf + IB * INB + blk * DYB + (pb + 32 * j) * 64 + g * 16) = RD[blk][j];
+          *reinterpret_cast<u32x4*>(buf + IB * INB + blk * DYB + (pb + 64 * j) * 64 + g * 16) = S.rd[blk][j];
     };
-    issue(0);
-    commit(smem);
-    if (nstage > 1) issue(1);
+    const int last = nstage - 1;
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(min(j, last), R[j]);
+    commit(smem, R[0]);
+    issue(min(D, last), R[0]);
     __syncthreads();
-    int cur = 0;
-    for (int s = 0; s < nstage; ++s) {
-      if (s + 1 < nstage) commit(smem + (cur ^ 1) * STAGEB);
-      if (s + 2 < nstage) issue(s + 2);
-      __syncthreads();
-      cur ^= 1;
+    for (int s0 = 0; s0 < nstage; s0 += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int cs = s0 + j;
+        if (cs < nstage) {
+          const int nx = cs + 1;
+          if (nx < nstage) commit(smem + (nx & 1) * STAGEB, R[(j + 1) % D]);
+          issue(min(nx + D, last), R[(j + 1) % D]);
+          __syncthreads();
+        }
+      }
     }
     return;
   }
@@ -260,7 +279,7 @@ template <int TAPS, int CB, int IB, int TH>
 static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   constexpr int halo = TAPS == 9 ? 1 : 0;
   constexpr int stage = IB * (TH + 2 * halo) * (32 + 2 * halo) * 64 + CB * TH * 32 * 64;
-  constexpr int lds = 2 * stage;
+  constexpr int lds = 2 * stage + 2 * 32 * IB * (int)sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<TAPS, CB, IB, TH>),
@@ -274,7 +293,7 @@ static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   if (gx > p.ntiles) gx = p.ntiles;
   p.per_wg = (p.ntiles + gx - 1) / gx;
   gx = (p.ntiles + p.per_wg - 1) / p.per_wg;
-  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH>), dim3(gx, gy, gz), dim3(384), lds, s, p);
+  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH>), dim3(gx, gy, gz), dim3(512), lds, s, p);
 }
 
 // returns 1 when taken, 0 when the shape is not eligible, <0 on error
