@@ -24,9 +24,22 @@ struct Igemm2Params {
   bf16_t* y0; bf16_t* y1; float* stats; const float* bias;
   int n, h, w, c0, c1, cout, split, xf0, xf1, in_mode, out_mode;
   int tiles_x, tiles_y, nblk, nitems, per_wg, nch, nk16;
+  unsigned long long* trace;  // diagnostic builds only (-DOCT_TRACE): s_memtime stamps of workgroup 0
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef OCT_TRACE
+#define TRACE(slot, idx)                                                                              \
+  do {                                                                                                \
+    if (p.trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (idx) < 256)                          \
+      p.trace[(slot) * 256 + (idx)] = __builtin_amdgcn_s_memtime();                                    \
+  } while (0)
+static unsigned long long* g_trace = nullptr;
+extern "C" void oct_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }
+#else
+#define TRACE(slot, idx) do {} while (0)
+#endif
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -62,6 +75,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   const int it1 = min(it0 + p.per_wg, p.nitems);
   if (it0 >= it1) return;
   const int nstage = (it1 - it0) * p.nch;
+  const int nstage_pad = (nstage + 3) / 4 * 4;   // producer ring depth D = 4
 
   // BN scale/shift of every input channel live in LDS: reading them with ds_read keeps them off the
   // vmcnt queue (a global load issued at commit time would be YOUNGER than the prefetched stages and
@@ -131,7 +145,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       const int ch = sidx - (sidx / p.nch) * p.nch;
       int cg = ch * 32 + grp * 8;
       if (p.in_mode == OCT_IN_S2D) cg -= ((ch * 32) / p.c0) * p.c0;
-      const bool first = p.in_mode == OCT_IN_S2D || cg < p.c0;
+      // wave-uniform on purpose (a 32-channel chunk lies in one source): a per-lane select between the
+      // two kernel arguments would become a VECTOR load + s_waitcnt vmcnt(0) in the middle of the ring
+      const bool first = p.in_mode == OCT_IN_S2D || ch * 32 < p.c0;
       const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
       float s[8], b[8];
       if (xf) {
@@ -146,7 +162,12 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         const int pix = pbase + 64 * i;
         if (pix < NPIX) {
           u32x4 v = Rr[i];
-          if (xf) {
+#ifndef ABL_NO_XFORM
+          if (xf)
+#else
+          if (xf && p.n == 12345)
+#endif
+          {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float lo = fmaxf(fmaf(bf16lo(v[j]), s[2 * j], b[2 * j]), 0.f);
@@ -168,18 +189,22 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     commit(0, buf0, R[0], vmask[0]);
     issue(min(D, last), R[0], vmask[0]);
     __syncthreads();
-    // stage k lives in ring slot k % D; while the MFMA waves work on stage cs, stage cs+1 is written to
-    // the other LDS buffer and its slot is refilled with the loads of stage cs+1+D
-    for (int s0 = 0; s0 < nstage; s0 += D) {
+    // Stage k lives in ring slot k % D; while the MFMA waves work on stage cs, stage cs+1 is written to
+    // the other LDS buffer and its slot is refilled with the loads of stage cs+1+D.  The body is
+    // branch-free (the stage count is padded to a multiple of D, both roles run the padded count,
+    // indices clamp to the last stage): with branches around the loads hipcc protects the ring
+    // registers with s_waitcnt vmcnt(0) and the prefetch collapses.
+    for (int s0 = 0; s0 < nstage_pad; s0 += D) {
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        const int cs = s0 + j;
-        if (cs < nstage) {
-          const int nx = cs + 1;
-          if (nx < nstage) commit(nx, buf0 + (nx & 1) * BUFB, R[(j + 1) % D], vmask[(j + 1) % D]);
-          issue(min(nx + D, last), R[(j + 1) % D], vmask[(j + 1) % D]);
-          __syncthreads();
-        }
+        const int nx = s0 + j + 1;
+        if (wave == 4) TRACE(4, nx - 1);
+        commit(min(nx, last), buf0 + (nx & 1) * BUFB, R[(j + 1) % D], vmask[(j + 1) % D]);
+        if (wave == 4) TRACE(5, nx - 1);
+        issue(min(nx + D, last), R[(j + 1) % D], vmask[(j + 1) % D]);
+        if (wave == 4) TRACE(6, nx - 1);
+        __syncthreads();
+        if (wave == 4) TRACE(7, nx - 1);
       }
     }
     if (STATS && WRES) __syncthreads();  // matches the barrier of the final statistics reduction
@@ -187,6 +212,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   }
 
   // ================================= MFMA waves (4) =================================
+  // each SIMD hosts one MFMA wave and one producer wave: the MFMA wave must win issue arbitration
+  // against the partner's VALU-dense staging code (static priority, MI355X_MICROARCH.md item 4)
+  __builtin_amdgcn_s_setprio(3);
   const int r = lane & 31, hh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -200,6 +228,14 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         const int tap = s >> 1, k16 = s & 1;
         wres[s][q] = M::load(p.wp + ((size_t)(nb * TAPS + tap) * p.nk16 + k16) * 512 + lane * 8);
       }
+    // Wait for the filter once and hide its origin from hipcc's waitcnt bookkeeping: otherwise every
+    // loop iteration re-waits "vmcnt(17..0)" for these registers, which in steady state means waiting
+    // for the previous tile's output STORES (vmcnt retires in order) before each MFMA.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int q = 0; q < NF; ++q) asm volatile("" : "+v"(wres[s][q]));
   }
 
   constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? 3 : ((MF * NF >= 4) ? 6 : 9));
@@ -214,10 +250,28 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       for (int i = 0; i < 16; ++i) { s1[q][i] = 0.f; s2[q][i] = 0.f; }
   }
 
+#ifdef OCT_TRACE
+  if (p.trace && blockIdx.x == 0 && wave == 0) {
+    // calibration: 64 back-to-back MFMAs on register operands, shader clock vs 100 MHz real time
+    f32x16 cacc[2];
+    for (int i = 0; i < 16; ++i) { cacc[0][i] = 0.f; cacc[1][i] = 0.f; }
+    Frag ca = M::load(p.wp + lane * 8), cb = M::load(p.wp + 512 + lane * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int i = 0; i < 64; ++i) M::mma(cacc[i & 1], ca, cb);
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    float sink = 0.f;
+    for (int i = 0; i < 16; ++i) sink += cacc[0][i] + cacc[1][i];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) { p.trace[2040] = t1 - t0; p.trace[2041] = r1 - r0; p.trace[2042] = (unsigned long long)(sink != 12345.f); p.trace[2043] = r0; }
+  }
+#endif
   __syncthreads();  // stage 0 is in LDS
   int cur = 0, pending_tile = -1, pending_nbi = 0, parity = 0;
   int item = it0, ch = 0;
-  for (int sidx = 0; sidx < nstage; ++sidx) {
+  for (int sidx = 0; sidx < nstage_pad; ++sidx) {
+    if (sidx >= nstage) { __syncthreads(); continue; }   // padded stages: keep the barrier count in step
     // flush the statistics of the previous item (written to wg_stats before the last barrier)
     if (STATS && !WRES && pending_tile >= 0) {
       const float* ws = wg_stats + (parity ^ 1) * (WM * 2 * NT);
@@ -241,6 +295,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
     }
 
+    if (wave == 0) TRACE(0, sidx);
     // ---- MFMA phase over the staged 32-channel chunk ----
     // Streamed weights ride a ring of PF fragments-steps that stays PF steps (>= ~700 cycles of MFMA
     // work) ahead of the consumer, across stage boundaries, so an L2 round trip never stalls a step.
@@ -263,21 +318,33 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
             for (int q = 0; q < NF; ++q) wring[j][q] = M::load(wbase + q * qstride + (j >> 1) * tstride + (j & 1) * 512);
         }
       }
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
+      // activation fragments ping-pong between two register sets: the ds_reads of step s+1 are issued
+      // before the MFMAs of step s, one lane base address + compile-time offsets for the whole stage
+      const unsigned char* lb = tb + ((wm * MF) * LW + r) * PIXB + 8 * hh * 2;
+      auto xoff = [](int s, int m) constexpr {
         const int tap = s >> 1, k16 = s & 1;
         const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
-        Frag xf[MF];
-#ifdef ABL_NO_XLOAD
-        if (s == 0)
-#endif
+        return ((m + ty) * LW + tx) * PIXB + k16 * 32;
+      };
+      // ring of LD+1 fragment sets: the reads of step s+LD are in flight while step s multiplies
+      constexpr int LD = (MF * NF >= 8) ? 1 : ((MF * NF >= 4) ? 2 : 3);
+      Frag xr[LD + 1][MF];
+#pragma unroll
+      for (int j = 0; j < LD; ++j)
+#pragma unroll
+        for (int m = 0; m < MF; ++m) xr[j][m] = M::load(lb + xoff(j, m));
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        if (s + LD < KSTEPS) {
+#pragma unroll
+          for (int m = 0; m < MF; ++m) xr[(s + LD) % (LD + 1)][m] = M::load(lb + xoff(s + LD, m));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads of step s+LD ahead of the MFMAs of step s
 #pragma unroll
         for (int m = 0; m < MF; ++m)
-          xf[m] = M::load(tb + ((wm * MF + m + ty) * LW + (r + tx)) * PIXB + (k16 * 16 + 8 * hh) * 2);
 #pragma unroll
-        for (int m = 0; m < MF; ++m)
-#pragma unroll
-          for (int q = 0; q < NF; ++q) M::mma(acc[m][q], WRES ? wres[s][q] : wring[s % PF][q], xf[m]);
+          for (int q = 0; q < NF; ++q)
+            M::mma(acc[m][q], WRES ? wres[s][q] : wring[s % PF][q], xr[s % (LD + 1)][m]);
 #ifndef ABL_NO_WLOAD
         if (!WRES) {
           const int s2 = s + PF;  // refill the slot just consumed
@@ -291,6 +358,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       }
     }
 
+    if (wave == 0) TRACE(1, sidx);
     // ---- epilogue of an item: NHWC stores, BN sums ----
     if (ch == p.nch - 1) {
       int t = tile;
@@ -334,7 +402,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
             auto a = __builtin_amdgcn_permlane32_swap(lo0, lo1, false, false);
             auto b = __builtin_amdgcn_permlane32_swap(hi0, hi1, false, false);
             const u32x4 v = {a[0], b[0], a[1], b[1]};
+#ifndef ABL_NO_STORE
             *reinterpret_cast<u32x4*>(row + 8 * g + 8 * hh) = v;
+#else
+            if (v[0] == 0x12345678u && v[1] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(row + 8 * g + 8 * hh) = v;
+#endif
           }
           if (STATS) {
 #pragma unroll
@@ -364,7 +436,12 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       }
     }
 
+    if (wave == 0) TRACE(2, sidx);
     __syncthreads();
+    if (wave == 0) TRACE(3, sidx);
+#ifdef OCT_TRACE
+    if (p.trace && blockIdx.x == 0 && wave == 0 && lane == 0 && sidx == nstage - 1) p.trace[2044] = __builtin_amdgcn_s_memrealtime();
+#endif
     cur ^= 1;
     if (++ch == p.nch) { ch = 0; ++item; }
   }
@@ -468,6 +545,11 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
   p.wp = (const bf16_t*)a->wpacked; p.y0 = (bf16_t*)a->y0; p.y1 = (bf16_t*)a->y1;
   p.stats = d->want_stats ? a->stat_partials : nullptr;
   p.bias = a->bias; p.in_mode = d->in_mode; p.out_mode = d->out_mode;
+#ifdef OCT_TRACE
+  p.trace = g_trace;
+#else
+  p.trace = nullptr;
+#endif
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.cout = d->cout; p.split = d->split;
   p.xf0 = d->xform0; p.xf1 = d->xform1;
   p.tiles_x = d->w / 32; p.tiles_y = d->h / 8; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;

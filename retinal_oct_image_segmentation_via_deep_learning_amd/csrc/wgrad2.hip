@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   const int t0 = blockIdx.x * p.per_wg, t1 = min(t0 + p.per_wg, p.ntiles);
   if (t0 >= t1) return;
   const int nstage = t1 - t0;
+  const int nstage_pad = (nstage + 3) / 4 * 4;   // producer ring depth D = 4
 
   // BN scale/shift of this workgroup's input channels in LDS (kept off the in-order vmcnt queue)
   float* const sxf = reinterpret_cast<float*>(smem + 2 * STAGEB);   // [2][32*IB]
@@ -188,22 +189,21 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     commit(smem, R[0]);
     issue(min(D, last), R[0]);
     __syncthreads();
-    for (int s0 = 0; s0 < nstage; s0 += D) {
+    // branch-free steady state over the padded stage count (see igemm2.hip)
+    for (int s0 = 0; s0 < nstage_pad; s0 += D) {
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        const int cs = s0 + j;
-        if (cs < nstage) {
-          const int nx = cs + 1;
-          if (nx < nstage) commit(smem + (nx & 1) * STAGEB, R[(j + 1) % D]);
-          issue(min(nx + D, last), R[(j + 1) % D]);
-          __syncthreads();
-        }
+        const int nx = s0 + j + 1;
+        commit(smem + (nx & 1) * STAGEB, R[(j + 1) % D]);
+        issue(min(nx + D, last), R[(j + 1) % D]);
+        __syncthreads();
       }
     }
     return;
   }
 
   // ================================ MFMA waves ================================
+  __builtin_amdgcn_s_setprio(3);  // win issue arbitration against the co-resident producer wave
   const int pair = wave % PAIRS, psx = wave / PAIRS;
   const int cb = pair / IB, ib = pair % IB;
   const int g4 = lane >> 4, li = lane & 15;
@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
 
   __syncthreads();
   int cur = 0;
-  for (int s = 0; s < nstage; ++s) {
+  for (int s = 0; s < nstage_pad; ++s) {
+    if (s >= nstage) { __syncthreads(); continue; }   // padded stages keep the barrier count in step
     const unsigned char* in_t = smem + cur * STAGEB + ib * INB + lane_off;
     const unsigned char* dy_t = smem + cur * STAGEB + IB * INB + cb * DYB + lane_off;
 #pragma unroll 1
