@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct V2Plan { bool ok; int nt; bool wres; int grid; int per_wg; int nitems; int nblk; int stat_rows; };
+struct V2Plan { bool ok; int nt; int th; bool wres; int grid; int per_wg; int nitems; int nblk; int stat_rows; };
 
 static bool v2_enabled() {
   static int on = -1;
@@ -506,7 +506,9 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   if (pl.nt == 0) { pl.ok = false; return pl; }
   pl.wres = (d->taps == 9) && (cin == 32) && (d->cout == pl.nt) && pl.nt <= 64;
   pl.nblk = d->cout / pl.nt;
-  const int ntiles = (d->w / 32) * (d->h / 8) * d->n;
+  // Cout = 32 (full-resolution, HBM-bound layers): 16-row tiles halve the halo overhead per output pixel
+  pl.th = (d->taps == 9 && pl.nt == 32 && (d->h % 16) == 0) ? 16 : 8;
+  const int ntiles = (d->w / 32) * (d->h / pl.th) * d->n;
   pl.nitems = ntiles * pl.nblk;
   int target = 512;  // 2 workgroups per CU
   if (target > pl.nitems) target = pl.nitems;
@@ -552,7 +554,7 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
 #endif
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.cout = d->cout; p.split = d->split;
   p.xf0 = d->xform0; p.xf1 = d->xform1;
-  p.tiles_x = d->w / 32; p.tiles_y = d->h / 8; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;
+  p.tiles_x = d->w / 32; p.tiles_y = d->h / pl.th; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;
   const int ktot = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
   p.nch = ktot / 32; p.nk16 = ktot / 16;
   hipStream_t s = as_stream(stream);
@@ -560,6 +562,8 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
     if (pl.nt == 32) launch_v2_1x1<4, 1, 2, 1>(p, pl.grid, s);
     else if (pl.nt == 64) launch_v2_1x1<2, 2, 4, 1>(p, pl.grid, s);
     else launch_v2_1x1<2, 2, 4, 2>(p, pl.grid, s);
+  } else if (pl.nt == 32 && pl.th == 16) {
+    if (pl.wres) launch_v2<4, 1, 4, 1, true>(p, pl.grid, s); else launch_v2<4, 1, 4, 1, false>(p, pl.grid, s);
   } else if (pl.nt == 32) {
     if (pl.wres) launch_v2<4, 1, 2, 1, true>(p, pl.grid, s); else launch_v2<4, 1, 2, 1, false>(p, pl.grid, s);
   } else if (pl.nt == 64) {

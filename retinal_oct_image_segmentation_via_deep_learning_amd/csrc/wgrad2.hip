@@ -230,21 +230,27 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     if (s >= nstage) { __syncthreads(); continue; }   // padded stages keep the barrier count in step
     const unsigned char* in_t = smem + cur * STAGEB + ib * INB + lane_off;
     const unsigned char* dy_t = smem + cur * STAGEB + IB * INB + cb * DYB + lane_off;
-#pragma unroll 1
-    for (int rr = 0; rr < ROWS; ++rr) {
-      const int ry = psx * ROWS + rr;
+    // flattened (row, half, tap) sequence with the transposed reads running two MFMAs ahead
+    constexpr int NK = ROWS * 2;                 // k-steps (16 pixels) of this wave per stage
+    auto a_off = [&](int k) { return ((psx * ROWS + (k >> 1)) * TW + (k & 1) * 16) * 64; };
+    auto b_off = [&](int k, int t) {
+      const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
+      return ((psx * ROWS + (k >> 1) + ty) * LW + (k & 1) * 16 + tx) * 64;
+    };
+    constexpr int NSEQ = NK * TAPS;
+    bf16x8 bq[3];
+    bf16x8 aq[2];
+    aq[0] = tr_frag(dy_t + a_off(0));
+    bq[0] = tr_frag(in_t + b_off(0, 0));
+    if (NSEQ > 1) bq[1] = tr_frag(in_t + b_off(1 / TAPS, 1 % TAPS));
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int xs = half * 16;
-        const bf16x8 a = tr_frag(dy_t + (ry * TW + xs) * 64);
-        if (do_bias) M::mma(accb, a, ones);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-          const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
-          const bf16x8 b = tr_frag(in_t + ((ry + ty) * LW + xs + tx) * 64);
-          M::mma(acc[t], a, b);
-        }
-      }
+    for (int i = 0; i < NSEQ; ++i) {
+      const int k = i / TAPS, t = i % TAPS;
+      if (i + 2 < NSEQ) bq[(i + 2) % 3] = tr_frag(in_t + b_off((i + 2) / TAPS, (i + 2) % TAPS));
+      if (t == 0 && k + 1 < NK) aq[(k + 1) & 1] = tr_frag(dy_t + a_off(k + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_bias && t == 0) M::mma(accb, aq[k & 1], ones);
+      M::mma(acc[t], aq[k & 1], bq[i % 3]);
     }
     __syncthreads();
     cur ^= 1;
