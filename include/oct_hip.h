@@ -156,7 +156,8 @@ int oct_bn_relu_fwd(int dtype, const void* y, const float* scale, const float* s
 /* g = (da + route(dpool)) * [y*scale+shift > 0], written to g; partial sums of g and
  * g*xhat (xhat = (y-mean)*invstd) per workgroup into partials[nblocks][2][c].
  * da or dpool may be NULL (not both).  dpool is at (h/2, w/2); the gradient goes to the first
- * maximum of each 2x2 window (ATen max_pool2d tie rule).  g may alias da.                    */
+ * maximum of each 2x2 window (ATen max_pool2d tie rule).  g may alias da; without dpool g may be
+ * NULL (reduce only: no masked copy is written, oct_bn_bwd_apply re-derives the mask).           */
 int oct_dact_bn_reduce(int dtype, const void* da, const void* dpool, const void* y,
                        const float* scale, const float* shift, const float* mean,
                        const float* invstd, void* g, float* partials, int n, int h, int w, int c,
@@ -167,9 +168,10 @@ int oct_bn_bwd_finalize(const float* partials, int nblocks, int c, double count,
                         const float* gamma, const float* mean, const float* invstd,
                         float* dgamma, float* dbeta, float* coef /* [3][c] */, int accumulate,
                         void* stream);
-/* dy = coef0*g + coef1*y + coef2, in place over g */
-int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, size_t npix, int c,
-                     void* stream);
+/* dy = coef0*g + coef1*y + coef2, in place over g.  With scale/shift != NULL, g holds dA and the ReLU
+ * mask [y*scale+shift > 0] is applied here (pairs with oct_dact_bn_reduce(g = NULL), reduce-only). */
+int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const float* scale,
+                     const float* shift, size_t npix, int c, void* stream);
 /* per-channel sum over pixels of an NHWC tensor (bias gradient of ConvTranspose2d) */
 int oct_channel_sum(int dtype, const void* x, float* out, size_t npix, int c, int accumulate,
                     void* stream);

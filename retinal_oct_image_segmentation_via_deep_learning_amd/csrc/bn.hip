@@ -277,7 +277,7 @@ __global__ void dact_bn_reduce_kernel(const T* da, const T* __restrict__ dpool, 
         a1[j] = gr;
         a2[j] = gr * ((yv[j] - mu[j]) * is[j]);
       }
-      store_vec<T, V>(g_out + pix * c + g * V, gv);
+      if (g_out) store_vec<T, V>(g_out + pix * c + g * V, gv);  // reduce-only mode: bn_bwd_apply re-derives the mask
     }
     if (reg_path) {
 #pragma unroll
@@ -362,7 +362,8 @@ extern "C" int oct_dact_bn_reduce_blocks(int n, int h, int w, int c, int has_poo
 extern "C" int oct_dact_bn_reduce(int dtype, const void* da, const void* dpool, const void* y, const float* scale,
                                   const float* shift, const float* mean, const float* invstd, void* g,
                                   float* partials, int n, int h, int w, int c, void* stream) {
-  OCT_CHECK(y && scale && shift && mean && invstd && g && partials, "oct_dact_bn_reduce: null pointer");
+  OCT_CHECK(y && scale && shift && mean && invstd && partials, "oct_dact_bn_reduce: null pointer");
+  OCT_CHECK(g || !dpool, "oct_dact_bn_reduce: the pooled variant must write g");
   OCT_CHECK(da || dpool, "oct_dact_bn_reduce: need da or dpool");
   OCT_CHECK(n > 0 && h > 0 && w > 0 && c > 0, "oct_dact_bn_reduce: bad shape");
   OCT_CHECK(!dpool || ((h % 2 == 0) && (w % 2 == 0)), "oct_dact_bn_reduce: pooled layer needs even h, w");
@@ -439,8 +440,11 @@ extern "C" int oct_bn_bwd_finalize(const float* partials, int nblocks, int c, do
   return oct_check_launch("bn_bwd_finalize");
 }
 
+// masked != 0: `g` holds dA (gradient w.r.t. the activation); the ReLU mask [y*scale+shift > 0] is
+// re-derived here, so the reduction pass before it never has to write a masked copy.
 template <typename T, int V>
-__global__ void bn_bwd_apply_kernel(T* g, const T* __restrict__ y, const float* __restrict__ coef, size_t npix, int c) {
+__global__ void bn_bwd_apply_kernel(T* g, const T* __restrict__ y, const float* __restrict__ coef,
+                                    const float* __restrict__ scale, const float* __restrict__ shift, size_t npix, int c) {
   const int G = c / V;
   const size_t total = npix * G;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -449,18 +453,26 @@ __global__ void bn_bwd_apply_kernel(T* g, const T* __restrict__ y, const float* 
     ldv<float, V>(coef + gi * V, k0); ldv<float, V>(coef + c + gi * V, k1); ldv<float, V>(coef + 2 * c + gi * V, k2);
     ldv<T, V>(g + pix * c + gi * V, gv);
     ldv<T, V>(y + pix * c + gi * V, yv);
+    if (scale) {
+      float sc[V], sh[V];
+      ldv<float, V>(scale + gi * V, sc); ldv<float, V>(shift + gi * V, sh);
+#pragma unroll
+      for (int j = 0; j < V; ++j) gv[j] = fmaf(yv[j], sc[j], sh[j]) > 0.f ? gv[j] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) gv[j] = fmaf(k0[j], gv[j], fmaf(k1[j], yv[j], k2[j]));
     store_vec<T, V>(g + pix * c + gi * V, gv);
   }
 }
-extern "C" int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, size_t npix, int c, void* stream) {
+extern "C" int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const float* scale,
+                                const float* shift, size_t npix, int c, void* stream) {
   OCT_CHECK(g && y && coef && npix > 0 && c > 0, "oct_bn_bwd_apply: bad args");
+  OCT_CHECK((scale == nullptr) == (shift == nullptr), "oct_bn_bwd_apply: scale/shift mismatch");
   const int v = vec_width(c);
   const int blocks = ew_blocks(npix, c / v);
   hipStream_t s = as_stream(stream);
 #define LAUNCH(T, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(blocks), dim3(EW_THREADS), 0, s, (T*)g, \
-                                        (const T*)y, coef, npix, c)
+                                        (const T*)y, coef, scale, shift, npix, c)
   if (dtype == OCT_DT_BF16) { if (v == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 1); }
   else if (dtype == OCT_DT_F32) { if (v == 8) LAUNCH(float, 8); else LAUNCH(float, 1); }
   else OCT_CHECK(false, "oct_bn_bwd_apply: bad dtype");

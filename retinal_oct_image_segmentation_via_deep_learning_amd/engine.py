@@ -304,12 +304,14 @@ class UNetEngine:
         lib = L.lib()
         n, h, w, c = rec.n, rec.h, rec.w, rec.cout
         dev = rec.y.device
+        pooled = dpool is not None
         g = da if da is not None else self._act(n, h, w, c, dev)
-        nblk = lib.oct_dact_bn_reduce_blocks(n, h, w, c, 1 if dpool is not None else 0)
+        nblk = lib.oct_dact_bn_reduce_blocks(n, h, w, c, 1 if pooled else 0)
         partials = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+        # non-pooled layers: reduce only (no masked copy is written); the apply pass re-derives the mask
         L.check(lib.oct_dact_bn_reduce(self.dt, L.ptr(da), L.ptr(dpool), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
                                        rec.bn.shift.data_ptr(), rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(),
-                                       g.data_ptr(), partials.data_ptr(), n, h, w, c, _stream()),
+                                       g.data_ptr() if pooled else None, partials.data_ptr(), n, h, w, c, _stream()),
                 "oct_dact_bn_reduce")
         coef = torch.empty((3, c), dtype=torch.float32, device=dev)
         L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, c, float(n * h * w), self._P[rec.gkey].data_ptr(),
@@ -318,8 +320,10 @@ class UNetEngine:
                 "oct_bn_bwd_finalize")
         if self.debug is not None:
             self.debug["g:" + rec.wkey] = g.float().clone()
-        L.check(lib.oct_bn_bwd_apply(self.dt, g.data_ptr(), rec.y.data_ptr(), coef.data_ptr(), n * h * w, c,
-                                     _stream()), "oct_bn_bwd_apply")
+        L.check(lib.oct_bn_bwd_apply(self.dt, g.data_ptr(), rec.y.data_ptr(), coef.data_ptr(),
+                                     None if pooled else rec.bn.scale.data_ptr(),
+                                     None if pooled else rec.bn.shift.data_ptr(), n * h * w, c, _stream()),
+                "oct_bn_bwd_apply")
         if self.debug is not None:
             self.debug["dy:" + rec.wkey] = g.float().clone()
             self.debug["y:" + rec.wkey] = rec.y.float().clone()

@@ -261,7 +261,7 @@ def test_bn_forward_pool_backward(env, dt, shape):
         L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, c, float(n * h * w), gammad.data_ptr(),
                                         mean.data_ptr(), invstd.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
                                         coef.data_ptr(), 0, st))
-        L.check(lib.oct_bn_bwd_apply(edt, g.data_ptr(), yd.data_ptr(), coef.data_ptr(), n * h * w, c, st))
+        L.check(lib.oct_bn_bwd_apply(edt, g.data_ptr(), yd.data_ptr(), coef.data_ptr(), None, None, n * h * w, c, st))
         torch.cuda.synchronize()
         dtot = (da.astype(np.float64) if use_da else 0) + (O.maxpool2x2_bwd(dp.astype(np.float64), idx, a.shape) if use_dp else 0)
         dz = dtot * (z > 0)
