@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // vmcnt queue (a global load issued at commit time would be YOUNGER than the prefetched stages and
   // waiting for it would drain the whole ring -- vmcnt retires in order)
   float* const sxf = reinterpret_cast<float*>(smem + 2 * BUFB) + (2 * WM * 2 * NT + 4);
+  unsigned char* const oscr = smem + 2 * BUFB + (2 * WM * 2 * NT + 4) * 4 + 2 * 1024 * 4;  // 4 waves x 32 px x 80 B
+  static_assert((2 * BUFB + (2 * WM * 2 * NT + 4) * 4) % 16 == 0, "scratch must stay 16-B aligned");
+  float* const sbias = reinterpret_cast<float*>(oscr + 4 * 32 * 80);   // [cout/4] deconv bias (D2S only)
   {
     const int kx = (p.in_mode == OCT_IN_S2D) ? p.c0 : p.c0 + p.c1;
     for (int i = tid; i < kx; i += 512) {
@@ -89,12 +92,15 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       sxf[i] = xf ? (first ? p.sc0[i] : p.sc1[i - p.c0]) : 1.f;
       sxf[kx + i] = xf ? (first ? p.sh0[i] : p.sh1[i - p.c0]) : 0.f;
     }
+    if (p.out_mode == OCT_OUT_D2S && p.bias)
+      for (int i = tid; i < (p.cout >> 2); i += 512) sbias[i] = p.bias[i];
   }
   __syncthreads();
 
   if (wave >= 4) {
     // =============================== producer waves (4) ===============================
     // global -> registers (issued two stages ahead) -> BN+ReLU -> LDS halo tile of the next stage
+    if (WRES) __builtin_amdgcn_s_setprio(2);
     const int ptid = tid - 256, grp = ptid & 3, pbase = ptid >> 2;
     constexpr int D = 4;            // stages of global loads in flight per producer thread
     u32x4 R[D][NSLOT];
@@ -214,7 +220,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // ================================= MFMA waves (4) =================================
   // each SIMD hosts one MFMA wave and one producer wave: the MFMA wave must win issue arbitration
   // against the partner's VALU-dense staging code (static priority, MI355X_MICROARCH.md item 4)
-  __builtin_amdgcn_s_setprio(3);
+  if (!WRES) __builtin_amdgcn_s_setprio(3);   // resident-weight (Cout <= 64, Cin = 32) kernels are producer-bound
   const int r = lane & 31, hh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -267,6 +273,52 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     if (lane == 0) { p.trace[2040] = t1 - t0; p.trace[2041] = r1 - r0; p.trace[2042] = (unsigned long long)(sink != 12345.f); p.trace[2043] = r0; }
   }
 #endif
+  // ---- deferred epilogue -------------------------------------------------------------------------
+  // At the end of an item the accumulators are only packed to bf16 (32 registers per 4 fragments);
+  // the LDS transpose + global stores of those fragments are interleaved with the MFMA steps of the
+  // NEXT stage (a fragment every ESTRIDE steps), where they ride in the issue slots the matrix pipe
+  // leaves free.  Done back to back they cost 3.5-5.8k cycles per item with the pipe idle.
+  constexpr bool DEFER = !WRES && NF == 1;   // register budget: 8 VGPRs per deferred fragment
+  constexpr int NFR = MF * NF;
+  constexpr int ESTRIDE = (KSTEPS - 2) / NFR > 0 ? (KSTEPS - 2) / NFR : 1;
+  constexpr int EHANDLED = ((KSTEPS - 1 + ESTRIDE - 1) / ESTRIDE) < NFR ? ((KSTEPS - 1 + ESTRIDE - 1) / ESTRIDE) : NFR;
+  unsigned packed[DEFER ? MF : 1][DEFER ? NF : 1][8];
+  bool pend = false;
+  int e_img = 0, e_tyi = 0, e_txi = 0, e_nbi = 0;
+  auto store_frag = [&](int m, int q) {   // fragment (m, q) of the item recorded in e_*
+    const int pm = DEFER ? m : 0, pq = DEFER ? q : 0;
+    const int cb0 = (e_nbi * (NT / 32) + wn * NF + q) * 32;
+    bf16_t* dst; int cd, co, dydx = 0;
+    if (p.out_mode == OCT_OUT_D2S) { cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0; }
+    else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
+    else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
+    // transpose the 32 pixel x 32 channel fragment through a wave-private LDS scratch so that
+    // consecutive lanes store consecutive 16-B chunks (whole 64-B channel rows per pixel)
+    unsigned char* sc = oscr + wave * (32 * 80);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 v = {packed[pm][pq][2 * g], packed[pm][pq][2 * g + 1]};
+      *reinterpret_cast<u32x2*>(sc + r * 80 + (8 * g + 4 * hh) * 2) = v;   // pixel r, channels 8g+4hh..+3
+    }
+    const int oy = e_tyi * TH + wm * MF + m;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int chunk = lane + 64 * k;   // 128 chunks of 16 B: pixel = chunk / 4, part = chunk % 4
+      const int px = chunk >> 2, part = chunk & 3;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(sc + px * 80 + part * 16);
+      const int ox = e_txi * TW + px;
+      const size_t pix = (p.out_mode == OCT_OUT_D2S)
+                             ? ((size_t)e_img * (2 * p.h) + 2 * oy + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * ox + (dydx & 1)
+                             : ((size_t)e_img * p.h + oy) * p.w + ox;
+#ifndef ABL_NO_STORE
+      *reinterpret_cast<u32x4*>(dst + pix * cd + co + part * 8) = v;
+#else
+      if (v[0] == 0x12345678u && v[1] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(dst + pix * cd + co + part * 8) = v;
+#endif
+    }
+  };
+
   __syncthreads();  // stage 0 is in LDS
   int cur = 0, pending_tile = -1, pending_nbi = 0, parity = 0;
   int item = it0, ch = 0;
@@ -355,6 +407,14 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
             wring[s % PF][q] = M::load(wb + q * qstride + (s3 >> 1) * tstride + (s3 & 1) * 512);
         }
 #endif
+        if (DEFER && s >= 1 && (s - 1) % ESTRIDE == 0 && (s - 1) / ESTRIDE < NFR) {
+          if (pend) store_frag(((s - 1) / ESTRIDE) / NF, ((s - 1) / ESTRIDE) % NF);
+        }
+      }
+      if (DEFER && pend) {
+#pragma unroll
+        for (int idx = EHANDLED; idx < NFR; ++idx) store_frag(idx / NF, idx % NF);
+        pend = false;
       }
     }
 
@@ -372,11 +432,13 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0;
         } else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
         else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
+        // deconv bias from LDS (staged at kernel start): a global load here would put a vmcnt(0) --
+        // i.e. a drain of the weight ring and of all earlier output stores -- into every epilogue
         float bv[16];
         if (p.out_mode == OCT_OUT_D2S && p.bias) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co + 8 * g + 4 * hh);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + co + 8 * g + 4 * hh);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[4 * g + j] = b4[j];
           }
@@ -386,28 +448,12 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         }
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
-          const int oy = tyi * TH + wm * MF + m, ox = txi * TW + r;
-          const size_t pix = (p.out_mode == OCT_OUT_D2S)
-                                 ? ((size_t)img * (2 * p.h) + 2 * oy + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * ox + (dydx & 1)
-                                 : ((size_t)img * p.h + oy) * p.w + ox;
-          bf16_t* row = dst + pix * cd + co;
 #pragma unroll
-          for (int g = 0; g < 4; g += 2) {
-            unsigned lo0 = pack_bf16x2(acc[m][q][4 * g] + bv[4 * g], acc[m][q][4 * g + 1] + bv[4 * g + 1]);
-            unsigned hi0 = pack_bf16x2(acc[m][q][4 * g + 2] + bv[4 * g + 2], acc[m][q][4 * g + 3] + bv[4 * g + 3]);
-            unsigned lo1 = pack_bf16x2(acc[m][q][4 * g + 4] + bv[4 * g + 4], acc[m][q][4 * g + 5] + bv[4 * g + 5]);
-            unsigned hi1 = pack_bf16x2(acc[m][q][4 * g + 6] + bv[4 * g + 6], acc[m][q][4 * g + 7] + bv[4 * g + 7]);
-            // lanes 32-63 of (lo0,hi0) <-> lanes 0-31 of (lo1,hi1): afterwards the lower half-wave holds
-            // channels 8g..8g+7 and the upper half-wave 8g+8..8g+15 of its pixel, 16 contiguous bytes
-            auto a = __builtin_amdgcn_permlane32_swap(lo0, lo1, false, false);
-            auto b = __builtin_amdgcn_permlane32_swap(hi0, hi1, false, false);
-            const u32x4 v = {a[0], b[0], a[1], b[1]};
-#ifndef ABL_NO_STORE
-            *reinterpret_cast<u32x4*>(row + 8 * g + 8 * hh) = v;
-#else
-            if (v[0] == 0x12345678u && v[1] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(row + 8 * g + 8 * hh) = v;
-#endif
+          for (int g = 0; g < 4; ++g) {
+            packed[DEFER ? m : 0][DEFER ? q : 0][2 * g] = pack_bf16x2(acc[m][q][4 * g] + bv[4 * g], acc[m][q][4 * g + 1] + bv[4 * g + 1]);
+            packed[DEFER ? m : 0][DEFER ? q : 0][2 * g + 1] = pack_bf16x2(acc[m][q][4 * g + 2] + bv[4 * g + 2], acc[m][q][4 * g + 3] + bv[4 * g + 3]);
           }
+          if (!DEFER) { e_img = img; e_tyi = tyi; e_txi = txi; e_nbi = nbi; store_frag(m, q); }
           if (STATS) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -417,6 +463,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           }
         }
       }
+      if (DEFER) { e_img = img; e_tyi = tyi; e_txi = txi; e_nbi = nbi; pend = true; }
       if (STATS && !WRES) {
         float* ws = wg_stats + parity * (WM * 2 * NT);
 #pragma unroll
@@ -444,6 +491,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #endif
     cur ^= 1;
     if (++ch == p.nch) { ch = 0; ++item; }
+  }
+
+  if (DEFER && pend) {  // the last item's fragments
+#pragma unroll
+    for (int idx = 0; idx < NFR; ++idx) store_frag(idx / NF, idx % NF);
   }
 
   // ---- final statistics ----
@@ -526,14 +578,14 @@ int oct_conv_v2_stat_rows(const OctConvDesc* d) {
 template <int WM, int WN, int MF, int NF, bool WRES>
 static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * (p.c0 + p.c1)) * (int)sizeof(float);
+  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float);
   if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(512), lds, s, p);
   else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(512), lds, s, p);
 }
 template <int WM, int WN, int MF, int NF>
 static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  const int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * (p.c0 + p.c1)) * (int)sizeof(float);
+  const int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float);
   hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(512), lds, s, p);
 }
 

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["OCT_HIP_LIB"] = os.path.join(ROOT, "retinal_oct_image_segmentation_via_deep_learning_amd", "liboct_hip_TRACE.so")
+os.environ["OCT_HIP_LIB"] = os.path.join(ROOT, "retinal_oct_image_segmentation_via_deep_learning_amd", os.environ.get("TRACE_LIB", "liboct_hip_TRACE.so"))
 from retinal_oct_image_segmentation_via_deep_learning_amd import _lib as L, engine as E
 n, h, w, c0, c1, cout = (int(v) for v in sys.argv[1:7])
 stats_on = len(sys.argv) > 7
@@ -42,3 +42,8 @@ print("consumer: MFMA phase ", f(c_phase)); print("consumer: epilogue   ", f(c_e
 print("producer: commit     ", f(p_commit)); print("producer: issue      ", f(p_issue)); print("producer: barrier    ", f(p_bar))
 print("stage period         ", f(stage))
 print("first 10 stages: phase", c_phase[:10], "epi", c_epi[:10], "cbar", c_bar[:10], "commit", p_commit[:10], "pbar", p_bar[:10])
+if os.environ.get("TRACE_FULL"):
+    np.set_printoptions(linewidth=250)
+    k = min(ns, 24)
+    print("phase ", c_phase[:k]); print("epi   ", c_epi[:k]); print("cbar  ", c_bar[:k]); print("commit", p_commit[:k]); print("issue ", p_issue[:k]); print("pbar  ", p_bar[:k]); print("period", stage[:k])
+    print("producer start rel. consumer phase start:", (t[4, :k] - t[0, :k]))
