@@ -209,6 +209,17 @@ int oct_head_dlogits(const OctHeadDesc* d, const void* y, const float* scale, co
                      const float* w, const float* b, const int64_t* target, const float* dice_coef,
                      float w_ce, const float* dprobs, void* dlogits, void* stream);
 
+/* Fused head backward (feat == 32 only, else OCT_E_INVALID -> use the pieces above): in one pass over
+ * y it writes dlogits (optional, NHWC dtype; needed by oct_conv_wgrad for dW), dA = W^T dlogits
+ * (NHWC dtype, [n,h,w,feat], UNMASKED: pair it with oct_bn_bwd_apply(scale, shift)), the BN-backward
+ * partial sums of the masked gradient [oct_head_blocks][2][feat] and the bias gradient (atomics into
+ * dbias[classes]; caller zeroes).                                                              */
+int oct_head_backward_fused(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, const float* w, const float* b,
+                            const int64_t* target, const float* dice_coef, float w_ce,
+                            const float* dprobs, void* dlogits, void* da, float* partials,
+                            float* dbias, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Layout / dtype helpers and the optimizer
  * ------------------------------------------------------------------------------------------ */

@@ -216,6 +216,114 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_dlogits_kernel(const HeadPa
   }
 }
 
+// Fused head backward for feat == 32: d(loss)/d(logits), the 1x1 data gradient dA = W^T dlogits, the
+// bias gradient, and the BatchNorm-backward partial sums of the layer feeding the head -- one pass
+// over y instead of (dlogits kernel + 1x1 implicit GEMM + ReLU/BN reduction pass).
+template <typename T, int CMAX>
+__global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const HeadParams p, const float* __restrict__ mean,
+                                                                       const float* __restrict__ invstd, T* __restrict__ da_out,
+                                                                       float* __restrict__ partials, float* __restrict__ dbias) {
+  constexpr int F = 32;
+  __shared__ float sw[OCT_MAX_CLASSES * F];
+  __shared__ float sb[OCT_MAX_CLASSES], ssc[F], ssh[F], smu[F], sis[F];
+  __shared__ float sdc[2 * OCT_MAX_CLASSES];
+  __shared__ float red[HEAD_THREADS / 64][2 * F + OCT_MAX_CLASSES];
+  for (int i = threadIdx.x; i < F; i += blockDim.x) { smu[i] = mean[i]; sis[i] = invstd[i]; }
+  if (p.dice_coef) for (int i = threadIdx.x; i < 2 * OCT_MAX_CLASSES; i += blockDim.x) sdc[i] = p.dice_coef[i];
+  head_load_consts(p, sw, sb, ssc, ssh);
+  const size_t hw = (size_t)p.h * p.wd, npix = (size_t)p.n * hw;
+  const float inv_n = 1.f / (float)npix;
+  float s1[F], s2[F], sdb[CMAX];
+#pragma unroll
+  for (int k = 0; k < F; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) sdb[c] = 0.f;
+  T* dl_out = reinterpret_cast<T*>(p.dlogits);
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+    const T* yp = reinterpret_cast<const T*>(p.y) + pix * F;
+    float yv[F], z[F], l[CMAX], pr[CMAX], dl[CMAX], dp[CMAX], m, lse;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) l[c] = (c < p.classes) ? sb[c] : 0.f;
+#pragma unroll
+    for (int f0 = 0; f0 < F; f0 += 8) {
+      load_vec<T, 8>(yp + f0, reinterpret_cast<float(&)[8]>(yv[f0]));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        z[f0 + j] = fmaf(yv[f0 + j], ssc[f0 + j], ssh[f0 + j]);
+        const float a = fmaxf(z[f0 + j], 0.f);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+          if (c < p.classes) l[c] = fmaf(sw[c * F + f0 + j], a, l[c]);
+      }
+    }
+    softmax_c<CMAX>(p.classes, l, pr, m, lse);
+    if (p.dprobs) {
+      const size_t img = pix / hw, off = pix - img * hw;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        dp[c] = (c < p.classes) ? p.dprobs[(img * p.classes + c) * hw + off] : 0.f;
+        dot = fmaf(pr[c], dp[c], dot);
+      }
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) dl[c] = pr[c] * (dp[c] - dot);
+    } else {
+      const int t = (int)p.target[pix];
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        dp[c] = 0.f;
+        if (p.dice_coef && c < p.classes) dp[c] = (c == t ? sdc[c] : 0.f) + sdc[OCT_MAX_CLASSES + c];
+        dot = fmaf(pr[c], dp[c], dot);
+      }
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) dl[c] = p.w_ce * (pr[c] - (c == t ? 1.f : 0.f)) * inv_n + pr[c] * (dp[c] - dot);
+    }
+    // the rest of the backward sees dlogits as stored (activation dtype), like the unfused path
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      dl[c] = (c < p.classes) ? to_f32(from_f32<T>(dl[c])) : 0.f;
+      sdb[c] += dl[c];
+      if (dl_out && c < p.classes) dl_out[pix * p.classes + c] = from_f32<T>(dl[c]);
+    }
+#pragma unroll
+    for (int f0 = 0; f0 < F; f0 += 8) {
+      float dav[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+          if (c < p.classes) d = fmaf(sw[c * F + f0 + j], dl[c], d);
+        const float dr = to_f32(from_f32<T>(d));   // dA as stored
+        dav[j] = d;
+        const float g = z[f0 + j] > 0.f ? dr : 0.f;
+        s1[f0 + j] += g;
+        s2[f0 + j] = fmaf(g, (yv[f0 + j] - smu[f0 + j]) * sis[f0 + j], s2[f0 + j]);
+      }
+      store_vec<T, 8>(da_out + pix * F + f0, dav);
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+    const float a = wave_sum(s1[k]), b = wave_sum(s2[k]);
+    if (lane == 0) { red[wave][k] = a; red[wave][F + k] = b; }
+  }
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const float a = wave_sum(sdb[c]);
+    if (lane == 0) red[wave][2 * F + c] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * F + CMAX; i += blockDim.x) {
+    float s = 0.f;
+    for (int wv = 0; wv < HEAD_THREADS / 64; ++wv) s += red[wv][i];
+    if (i < 2 * F) partials[(size_t)blockIdx.x * 2 * F + i] = s;            // [block][2][F]
+    else if (i - 2 * F < p.classes) atomicAdd(&dbias[i - 2 * F], s);
+  }
+}
+
 static int head_grid(const OctHeadDesc* d) {
   const size_t npix = (size_t)d->n * d->h * d->w;
   size_t b = (npix + HEAD_THREADS - 1) / HEAD_THREADS;
@@ -292,4 +400,31 @@ extern "C" int oct_head_dlogits(const OctHeadDesc* d, const void* y, const float
   hipStream_t s = as_stream(stream);
   HEAD_DISPATCH(head_dlogits_kernel, d, grid, s, p);
   return oct_check_launch("head_dlogits");
+}
+
+extern "C" int oct_head_backward_fused(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
+                                       const float* mean, const float* invstd, const float* w, const float* b,
+                                       const int64_t* target, const float* dice_coef, float w_ce, const float* dprobs,
+                                       void* dlogits, void* da, float* partials, float* dbias, void* stream) {
+  int rc = head_check(d, "oct_head_backward_fused");
+  if (rc) return rc;
+  OCT_CHECK(d->feat == 32, "oct_head_backward_fused: only feat == 32 is fused (got %d); use oct_head_dlogits", d->feat);
+  OCT_CHECK(y && scale && shift && mean && invstd && w && b && da && partials && dbias, "oct_head_backward_fused: null pointer");
+  OCT_CHECK(target || dprobs, "oct_head_backward_fused: need a target or dprobs");
+  HeadParams p = {};
+  p.y = y; p.scale = scale; p.shift = shift; p.w = w; p.b = b; p.target = target; p.dice_coef = dice_coef;
+  p.dprobs = dprobs; p.dlogits = dlogits; p.w_ce = w_ce;
+  p.n = d->n; p.h = d->h; p.wd = d->w; p.feat = d->feat; p.classes = d->classes;
+  const int grid = head_grid(d);
+  hipStream_t s = as_stream(stream);
+  const int cm = d->classes <= 2 ? 2 : d->classes <= 4 ? 4 : d->classes <= 8 ? 8 : 16;
+#define LAUNCH(T, C) hipLaunchKernelGGL((head_bwd_fused_kernel<T, C>), dim3(grid), dim3(HEAD_THREADS), 0, s, p, mean, \
+                                        invstd, (T*)da, partials, dbias)
+  if (d->dtype == OCT_DT_BF16) {
+    if (cm == 2) LAUNCH(bf16_t, 2); else if (cm == 4) LAUNCH(bf16_t, 4); else if (cm == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 16);
+  } else {
+    if (cm == 2) LAUNCH(float, 2); else if (cm == 4) LAUNCH(float, 4); else if (cm == 8) LAUNCH(float, 8); else LAUNCH(float, 16);
+  }
+#undef LAUNCH
+  return oct_check_launch("head_bwd_fused");
 }

@@ -299,20 +299,24 @@ class UNetEngine:
         return ctx, probs, amax, logits
 
     # ---- backward -------------------------------------------------------------------------------
-    def _bn_backward(self, rec: ConvRec, da, dpool, G, accumulate):
-        """da (and/or pooled gradient) wrt relu(bn(y)) -> dy in place; BN parameter grads."""
+    def _bn_backward(self, rec: ConvRec, da, dpool, G, accumulate, partials=None):
+        """da (and/or pooled gradient) wrt relu(bn(y)) -> dy in place; BN parameter grads.
+        partials: reduction already done by the producer of da (fused head backward)."""
         lib = L.lib()
         n, h, w, c = rec.n, rec.h, rec.w, rec.cout
         dev = rec.y.device
         pooled = dpool is not None
         g = da if da is not None else self._act(n, h, w, c, dev)
-        nblk = lib.oct_dact_bn_reduce_blocks(n, h, w, c, 1 if pooled else 0)
-        partials = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
-        # non-pooled layers: reduce only (no masked copy is written); the apply pass re-derives the mask
-        L.check(lib.oct_dact_bn_reduce(self.dt, L.ptr(da), L.ptr(dpool), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
-                                       rec.bn.shift.data_ptr(), rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(),
-                                       g.data_ptr() if pooled else None, partials.data_ptr(), n, h, w, c, _stream()),
-                "oct_dact_bn_reduce")
+        if partials is not None:
+            nblk = partials.shape[0]
+        else:
+            nblk = lib.oct_dact_bn_reduce_blocks(n, h, w, c, 1 if pooled else 0)
+            partials = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+            # non-pooled layers: reduce only (no masked copy is written); the apply pass re-derives the mask
+            L.check(lib.oct_dact_bn_reduce(self.dt, L.ptr(da), L.ptr(dpool), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
+                                           rec.bn.shift.data_ptr(), rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(),
+                                           g.data_ptr() if pooled else None, partials.data_ptr(), n, h, w, c, _stream()),
+                    "oct_dact_bn_reduce")
         coef = torch.empty((3, c), dtype=torch.float32, device=dev)
         L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, c, float(n * h * w), self._P[rec.gkey].data_ptr(),
                                         rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(), G[rec.gkey].data_ptr(),
@@ -345,9 +349,9 @@ class UNetEngine:
         self._conv(Src(dy, rec.cout), wp, cin, 9, n, h, w, d0, y1=d1, split=src.c0 if src.c1 else 0)
         return d0, d1
 
-    def _block_backward(self, level, da, dpool, G, accumulate, need_dx=True):
+    def _block_backward(self, level, da, dpool, G, accumulate, need_dx=True, partials=None):
         r1, r2 = self._ctx.convs[level]
-        dy2 = self._bn_backward(r2, da, dpool, G, accumulate)
+        dy2 = self._bn_backward(r2, da, dpool, G, accumulate, partials=partials)
         da1, _ = self._conv_backward(r2, dy2, G, accumulate)
         dy1 = self._bn_backward(r1, da1, None, G, accumulate)
         return self._conv_backward(r1, dy1, G, accumulate, need_dx=need_dx)
@@ -369,22 +373,39 @@ class UNetEngine:
             if ctx.target is None:
                 raise RuntimeError("backward without dprobs needs forward(target=...)")
             tgt, dc, w_ce = ctx.target, ctx.dice_coef, ctx.loss_cfg[0]
-        L.check(lib.oct_head_dlogits(C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(), rec.bn.shift.data_ptr(),
-                                     P["conv.weight"].data_ptr(), P["conv.bias"].data_ptr(), L.ptr(tgt), L.ptr(dc),
-                                     w_ce, L.ptr(dprobs), dl.data_ptr(), _stream()), "oct_head_dlogits")
-        # head parameter gradients and dA through the generic 1x1 machinery
         hsrc = Src(rec.y, f, rec.bn)
+        head_partials = None
+        bgrad = G["conv.bias"]
+        if f == 32:
+            # fused: dlogits + dA = W^T dlogits + bias gradient + BN-backward partial sums in one pass over y
+            if not accumulate:
+                bgrad.zero_()
+            da = self._act(n, h, w, f, dev)
+            nb = lib.oct_head_blocks(C.byref(hd))
+            head_partials = torch.empty((nb, 2, f), dtype=torch.float32, device=dev)
+            L.check(lib.oct_head_backward_fused(
+                C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(), rec.bn.shift.data_ptr(),
+                rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(), P["conv.weight"].data_ptr(),
+                P["conv.bias"].data_ptr(), L.ptr(tgt), L.ptr(dc), w_ce, L.ptr(dprobs), dl.data_ptr(), da.data_ptr(),
+                head_partials.data_ptr(), bgrad.data_ptr(), _stream()), "oct_head_backward_fused")
+        else:
+            L.check(lib.oct_head_dlogits(C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
+                                         rec.bn.shift.data_ptr(), P["conv.weight"].data_ptr(),
+                                         P["conv.bias"].data_ptr(), L.ptr(tgt), L.ptr(dc), w_ce, L.ptr(dprobs),
+                                         dl.data_ptr(), _stream()), "oct_head_dlogits")
+            L.check(lib.oct_channel_sum(self.dt, dl.data_ptr(), bgrad.data_ptr(), n * h * w, ncls, int(accumulate),
+                                        _stream()), "oct_channel_sum")
+            wp = self._pack("conv.weight", P["conv.weight"], L.PACK_1X1_DGRAD, ncls, f)
+            da = self._act(n, h, w, f, dev)
+            self._conv(Src(dl, ncls), wp, f, 1, n, h, w, da)
+        # head weight gradient through the generic 1x1 wgrad
         dwp = self._wgrad(hsrc, dl, ncls, 1, n, h, w)
         self._unpack(L.PACK_1X1_FPROP, dwp, G["conv.weight"], ncls, f, accumulate)
-        L.check(lib.oct_channel_sum(self.dt, dl.data_ptr(), G["conv.bias"].data_ptr(), n * h * w, ncls,
-                                    int(accumulate), _stream()), "oct_channel_sum")
-        wp = self._pack("conv.weight", P["conv.weight"], L.PACK_1X1_DGRAD, ncls, f)
-        da = self._act(n, h, w, f, dev)
-        self._conv(Src(dl, ncls), wp, f, 1, n, h, w, da)
         dskip = {}
         for di in range(4):  # dec1, dec2, dec3, dec4
             k = di + 1
-            du, dskip[k] = self._block_backward(f"dec{k}", da, None, G, accumulate)
+            du, dskip[k] = self._block_backward(f"dec{k}", da, None, G, accumulate,
+                                                partials=head_partials if k == 1 else None)
             prev, u = ctx.ups[k]
             cin_d, cout_d = prev.cout, prev.cout // 2
             hl, wl = prev.h, prev.w

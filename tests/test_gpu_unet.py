@@ -153,6 +153,46 @@ def test_bf16_sgd_trajectory_descends_like_reference(golden_dir, name):
     assert losses[-1] < losses[0]
 
 
+def test_default_width_network_matches_oracle_and_bf16_tracks_f32():
+    """init_features = 32 (the BASELINE configuration) takes kernel paths the small fixtures do not:
+    the fused head backward (feat == 32) and, in bf16, the pipelined conv / wgrad / first-layer
+    kernels.  fp32 mode is checked against the fp64 oracle, bf16 mode against fp32 mode."""
+    from oracle import ref_cpu
+    from retinal_oct_image_segmentation_via_deep_learning_amd import UNet
+    torch.manual_seed(11)
+    model = UNet(1, 8, init_features=32, compute_dtype="f32").cuda().train()
+    state = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 1, 32, 64, generator=g)
+    t = torch.randint(0, 8, (2, 32, 64), generator=g)
+    loss, probs = model.forward_backward(x.cuda(), t.cuda(), 1.0, 0.25, want_probs=True)
+    net = ref_cpu.OracleUNet(state)
+    rp, (rl, _, _), rg = net.loss_and_grads(x.numpy(), t.numpy(), 1.0, 0.25)
+    assert np.abs(probs.cpu().numpy() - rp).max() < 2e-5
+    np.testing.assert_allclose(loss[0].item(), rl, rtol=2e-5)
+    g32 = {}
+    for k, p in model.named_parameters():
+        g32[k] = p.grad.detach().cpu().numpy().copy()
+        grad_close(g32[k], rg[k], k, 3e-3)
+    # bf16 on a regular shape (W % 32 == 0, H % 16 == 0 at every level would need 512 px; here the
+    # full-resolution and half-resolution levels are regular, deeper ones fall back to the generic kernels)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.cuda().set_compute_dtype("bf16")
+    x2 = torch.randn(2, 1, 128, 256, generator=g).cuda()
+    t2 = torch.randint(0, 8, (2, 128, 256), generator=g).cuda()
+    l16 = model.forward_backward(x2, t2, 1.0, 0.25).cpu().numpy()
+    g16 = {k: p.grad.detach().double().cpu().numpy().ravel() for k, p in model.named_parameters()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.cuda().set_compute_dtype("f32")
+    l32 = model.forward_backward(x2, t2, 1.0, 0.25).cpu().numpy()
+    np.testing.assert_allclose(l16, l32, rtol=5e-3)
+    cos = []
+    for k, p in model.named_parameters():
+        a, b = g16[k], p.grad.detach().double().cpu().numpy().ravel()
+        cos.append(float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)))
+    assert min(cos) > 0.6 and np.mean(cos) > 0.88, (min(cos), np.mean(cos))
+
+
 def test_api_errors_like_reference(golden_dir):
     from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment.YNet_2022 import UNet, get_model
     z = np.load(os.path.join(golden_dir, "api.npz"))
