@@ -125,6 +125,9 @@ typedef struct OctWgradArgs {
   const void* dy;
   float* dwp;
   float* dbias; /* optional: += sum over pixels of dy per real output channel (bias gradient); caller zeroes */
+  /* optional fused BatchNorm-backward apply (first layer only, OCT_E_INVALID elsewhere): when dy_coef != NULL,
+   * `dy` holds dA and the kernel forms dy = coef0*[y*scale+shift>0]*dA + coef1*y + coef2 on the fly */
+  const void* dy_y; const float* dy_coef; const float* dy_scale; const float* dy_shift;
 } OctWgradArgs;
 int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
 /* dwp -> torch-layout gradient.  mode: OCT_PACK_CONV_FPROP (grad[co][ci][tap]),

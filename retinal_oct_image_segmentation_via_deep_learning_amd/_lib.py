@@ -42,7 +42,8 @@ class WgradDesc(C.Structure):
 
 
 class WgradArgs(C.Structure):
-    _fields_ = [(k, c_void_p) for k in ("x0", "x1", "scale0", "shift0", "scale1", "shift1", "dy", "dwp", "dbias")]
+    _fields_ = [(k, c_void_p) for k in ("x0", "x1", "scale0", "shift0", "scale1", "shift1", "dy", "dwp", "dbias",
+                                                "dy_y", "dy_coef", "dy_scale", "dy_shift")]
 
 
 class HeadDesc(C.Structure):

@@ -80,7 +80,9 @@ __global__ void __launch_bounds__(256) first_fprop_kernel(const bf16_t* __restri
 
 template <int F>
 __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                          float* __restrict__ dwp, int n, int h, int w) {
+                                                          float* __restrict__ dwp, int n, int h, int w,
+                                                          const bf16_t* __restrict__ yraw, const float* __restrict__ coef,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift) {
   constexpr int G = F / 8;
   __shared__ float sacc[9 * F];
   for (int i = threadIdx.x; i < 9 * F; i += 256) sacc[i] = 0.f;
@@ -92,6 +94,15 @@ __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restri
     for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
   const size_t npix = (size_t)n * h * w, total = npix * G;
   const int g = threadIdx.x % G;  // 256 % G == 0: the channel group of a thread is loop invariant
+  // fused BN-backward apply: dy = k0*[z>0]*dA + k1*y + k2 (per-channel constants of this thread's group)
+  float k0[8], k1[8], k2[8], sc[8], sh[8];
+  if (coef) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      k0[j] = coef[g * 8 + j]; k1[j] = coef[F + g * 8 + j]; k2[j] = coef[2 * F + g * 8 + j];
+      sc[j] = scale[g * 8 + j]; sh[j] = shift[g * 8 + j];
+    }
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t pix = i / G;
     const int xx = pix % w;
@@ -100,6 +111,16 @@ __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restri
     float dv[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { dv[2 * j] = __uint_as_float(d[j] << 16); dv[2 * j + 1] = __uint_as_float(d[j] & 0xffff0000u); }
+    if (coef) {
+      const u32x4 yy = *reinterpret_cast<const u32x4*>(yraw + pix * F + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float yv = (j & 1) ? __uint_as_float(yy[j >> 1] & 0xffff0000u) : __uint_as_float(yy[j >> 1] << 16);
+        const float gm = fmaf(yv, sc[j], sh[j]) > 0.f ? dv[j] : 0.f;
+        // rounded to the activation dtype, exactly what the unfused apply pass would have stored
+        dv[j] = (float)(bf16_t)fmaf(k0[j], gm, fmaf(k1[j], yv, k2[j]));
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int ddy = t / 3 - 1, ddx = t % 3 - 1;
@@ -158,12 +179,14 @@ int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
 
 int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
   if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
+  if (a->dy_coef && (!a->dy_y || !a->dy_scale || !a->dy_shift)) { oct_set_error("oct_conv_wgrad: fused apply needs y, scale, shift"); return OCT_E_INVALID; }
   const size_t total = (size_t)d->n * d->h * d->w * (d->cout / 8);
   size_t b = (total + 255) / 256;
   if (b > 2048) b = 2048;
   hipStream_t s = as_stream(stream);
 #define LAUNCH(F) hipLaunchKernelGGL(first_wgrad_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
-                                     (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w)
+                                     (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
+                                     (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift)
   if (d->cout == 16) LAUNCH(16); else if (d->cout == 32) LAUNCH(32); else LAUNCH(64);
 #undef LAUNCH
   int rc = oct_check_launch("first_wgrad");

@@ -198,6 +198,7 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
   {
     int took = oct_first_wgrad(d, a, stream);
+    if (took == 0 && a->dy_coef) OCT_CHECK(false, "oct_conv_wgrad: the fused BN-backward apply is only implemented for the 1->F first layer in bf16");
     if (took == 0) took = oct_conv_wgrad_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
   }

@@ -163,7 +163,8 @@ class UNetEngine:
                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, 0, 0, 0, 1)
         return L.lib().oct_conv_stat_blocks(C.byref(d))
 
-    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None):
+    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None, fused_apply=None):
+        """fused_apply = (y, coef, scale, shift): `dy` holds dA and the kernel applies BN backward on load."""
         ktot = src.channels
         dwp = torch.zeros((taps, cout, ktot), dtype=torch.float32, device=dy.device)
         d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
@@ -172,7 +173,8 @@ class UNetEngine:
         a = L.WgradArgs(L.ptr(src.x0), L.ptr(src.x1),
                         L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                         L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
-                        L.ptr(dy), L.ptr(dwp), L.ptr(dbias))
+                        L.ptr(dy), L.ptr(dwp), L.ptr(dbias), *([L.ptr(t) for t in fused_apply] if fused_apply
+                                                                 else [None, None, None, None]))
         ev = self._prof_begin()
         L.check(L.lib().oct_conv_wgrad(C.byref(d), C.byref(a), _stream()), "oct_conv_wgrad")
         self._prof_end(ev, "wgrad")
@@ -299,7 +301,7 @@ class UNetEngine:
         return ctx, probs, amax, logits
 
     # ---- backward -------------------------------------------------------------------------------
-    def _bn_backward(self, rec: ConvRec, da, dpool, G, accumulate, partials=None):
+    def _bn_backward(self, rec: ConvRec, da, dpool, G, accumulate, partials=None, defer_apply=False):
         """da (and/or pooled gradient) wrt relu(bn(y)) -> dy in place; BN parameter grads.
         partials: reduction already done by the producer of da (fused head backward)."""
         lib = L.lib()
@@ -324,6 +326,8 @@ class UNetEngine:
                 "oct_bn_bwd_finalize")
         if self.debug is not None:
             self.debug["g:" + rec.wkey] = g.float().clone()
+        if defer_apply and not pooled:
+            return g, coef   # the consumer (first-layer wgrad) applies dy = k0*mask*dA + k1*y + k2 on load
         L.check(lib.oct_bn_bwd_apply(self.dt, g.data_ptr(), rec.y.data_ptr(), coef.data_ptr(),
                                      None if pooled else rec.bn.scale.data_ptr(),
                                      None if pooled else rec.bn.shift.data_ptr(), n * h * w, c, _stream()),
@@ -353,6 +357,16 @@ class UNetEngine:
         r1, r2 = self._ctx.convs[level]
         dy2 = self._bn_backward(r2, da, dpool, G, accumulate, partials=partials)
         da1, _ = self._conv_backward(r2, dy2, G, accumulate)
+        first_fused = (not need_dx and self.dtype == "bf16" and r1.src.channels == 1 and r1.src.bn0 is None
+                       and r1.cout in (16, 32, 64))
+        if first_fused:
+            # first layer: no data gradient, so dY1 has a single consumer -- the weight-gradient kernel
+            # applies the BN backward itself and the dY1 tensor is never written
+            da1, coef = self._bn_backward(r1, da1, None, G, accumulate, defer_apply=True)
+            dwp = self._wgrad(r1.src, da1, r1.cout, 9, r1.n, r1.h, r1.w,
+                              fused_apply=(r1.y, coef, r1.bn.scale, r1.bn.shift))
+            self._unpack(L.PACK_CONV_FPROP, dwp, G[r1.wkey], r1.cout, 1, accumulate)
+            return None, None
         dy1 = self._bn_backward(r1, da1, None, G, accumulate)
         return self._conv_backward(r1, dy1, G, accumulate, need_dx=need_dx)
 
