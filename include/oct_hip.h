@@ -245,6 +245,14 @@ int oct_confusion_counts(const void* y_true, const void* y_pred, int elem, size_
                          int64_t* out_i /* [6] device, zeroed by callee */,
                          double* out_f /* [6] device, zeroed by callee */, void* stream);
 
+/* Metrics/PixelError_based_metrics.py:3-37: out[0] = sum (double(t) - double(p))^2 (device double)      */
+int oct_sqdiff_sum(const void* y_true, const void* y_pred, int elem, size_t n, double* out, void* stream);
+/* Metrics/Biomarker_based_metrics.py:3-21: out[0] = sum over columns of |colsum(t) - colsum(p)| for a
+ * (rows, cols) view (axis 0 = rows).  unsigned_wrap != 0 reproduces numpy's uint64 wrap-around for
+ * unsigned inputs; bool masks pass elem 0 with unsigned_wrap = 0 (numpy sums bool in int64).          */
+int oct_column_absdiff_sum(const void* y_true, const void* y_pred, int elem, int unsigned_wrap, size_t rows,
+                           size_t cols, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

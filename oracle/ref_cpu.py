@@ -376,9 +376,29 @@ def specificity(y_true, y_pred):  # :50-63
     return c["tn"] / (c["tn"] + c["fp"] + 1e-7)
 
 
+def mean_squared_error(y_true, y_pred):  # PixelError_based_metrics.py:3-19
+    d = np.asarray(y_true).astype(float) - np.asarray(y_pred).astype(float)
+    return np.mean(d ** 2)
+
+
+def root_mean_squared_error(y_true, y_pred):  # :21-37
+    return np.sqrt(mean_squared_error(y_true, y_pred))
+
+
+def thickness_difference(y_true, y_pred):  # Biomarker_based_metrics.py:3-21 (numpy dtype semantics kept)
+    return np.mean(np.abs(np.sum(np.asarray(y_true), axis=0) - np.sum(np.asarray(y_pred), axis=0)))
+
+
+def vascularity_index(y_true, y_pred):  # :23-38
+    yt, yp = np.asarray(y_true), np.asarray(y_pred)
+    return np.abs(np.sum(yt) / yt.size - np.sum(yp) / yp.size)
+
+
 METRIC_FUNCS = {
     "region.dice_coefficient": dice_coefficient, "region.iou_score": iou_score,
     "region.precision": region_precision, "region.recall": region_recall,
     "cm.accuracy": accuracy, "cm.sensitivity": sensitivity,
     "cm.precision": cm_precision, "cm.specificity": specificity,
+    "pixel.mean_squared_error": mean_squared_error, "pixel.root_mean_squared_error": root_mean_squared_error,
+    "bio.thickness_difference": thickness_difference, "bio.vascularity_index": vascularity_index,
 }

@@ -27,6 +27,56 @@ def _canonical(dt: np.dtype) -> np.dtype:
     raise TypeError(f"unsupported mask dtype {dt}")
 
 
+def _prepare(y_true, y_pred, device=None):
+    """-> (yt, yp) contiguous device tensors of the kernel dtype, numpy result dtype, kernel dtype"""
+    if isinstance(y_true, torch.Tensor) or isinstance(y_pred, torch.Tensor):
+        yt = y_true if isinstance(y_true, torch.Tensor) else torch.as_tensor(np.asarray(y_true))
+        yp = y_pred if isinstance(y_pred, torch.Tensor) else torch.as_tensor(np.asarray(y_pred))
+        dev = device or (yt.device if yt.is_cuda else yp.device if yp.is_cuda else torch.device("cuda"))
+        npdt = np.result_type(_TORCH2NP[yt.dtype], _TORCH2NP[yp.dtype])
+        if yt.shape != yp.shape:
+            yt, yp = torch.broadcast_tensors(yt, yp)
+    else:
+        a, b = np.asarray(y_true), np.asarray(y_pred)
+        npdt = np.result_type(a.dtype, b.dtype)
+        if a.shape != b.shape:
+            a, b = np.broadcast_arrays(a, b)
+        dev = device or torch.device("cuda")
+        yt, yp = torch.from_numpy(np.ascontiguousarray(a)), torch.from_numpy(np.ascontiguousarray(b))
+    kdt = _canonical(npdt)
+    tdt = getattr(torch, kdt.name)
+    yt = yt.to(device=dev, dtype=tdt).contiguous()
+    yp = yp.to(device=dev, dtype=tdt).contiguous()
+    if yt.device.type != "cuda":
+        raise L.OctError("Metrics need a GPU: there is no CPU fallback on the product path")
+    return yt, yp, np.dtype(npdt), kdt
+
+
+def sqdiff_sum(y_true, y_pred):
+    """(sum (t-p)^2 in fp64, n) -- PixelError_based_metrics"""
+    yt, yp, _, kdt = _prepare(y_true, y_pred)
+    out = torch.empty(1, dtype=torch.float64, device=yt.device)
+    L.check(L.lib().oct_sqdiff_sum(yt.data_ptr(), yp.data_ptr(), _ELEM[kdt], yt.numel(), out.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), "oct_sqdiff_sum")
+    return float(out.item()), yt.numel()
+
+
+def column_absdiff_mean(y_true, y_pred):
+    """mean over columns of |sum_axis0 t - sum_axis0 p| with numpy's dtype semantics -- Biomarker thickness"""
+    yt, yp, npdt, kdt = _prepare(y_true, y_pred)
+    if yt.dim() == 0:
+        yt, yp = yt.reshape(1), yp.reshape(1)
+    rows = yt.shape[0]
+    cols = yt.numel() // max(rows, 1) if rows else 0
+    out = torch.empty(1, dtype=torch.float64, device=yt.device)
+    wrap = 1 if npdt.kind == "u" else 0   # numpy sums unsigned arrays in uint64: the difference wraps
+    L.check(L.lib().oct_column_absdiff_sum(yt.data_ptr(), yp.data_ptr(), _ELEM[kdt], wrap, rows, cols, out.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), "oct_column_absdiff_sum")
+    if yt.dim() == 1:   # axis-0 sum of a 1-D mask is a scalar: one "column"
+        return float(out.item()), npdt
+    return (float(out.item()) / cols if cols else float("nan")), npdt
+
+
 def confusion_sums(y_true, y_pred, device=None):
     """Returns (sums, n, float32_result): sums = [tp, t, p, tn, fp, fn] as python ints (integer
     masks, exact) or floats (float masks, fp64 accumulation)."""

@@ -93,6 +93,8 @@ SIGNATURES = {
     "oct_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_int,
                              c_void_p]),
     "oct_confusion_counts": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "oct_sqdiff_sum": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
+    "oct_column_absdiff_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -549,6 +549,7 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   const int cin = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
   pl.ok = d->dtype == OCT_DT_BF16 && (d->w % 32) == 0 && (d->h % 8) == 0 && (d->c0 % 32) == 0 &&
           (d->c1 % 32) == 0 && (d->cout % 32) == 0 && (d->split % 32) == 0;
+  pl.ok = pl.ok && (d->c0 + d->c1) <= 1024 && d->cout <= 4096;   // LDS tables: 2 x 1024 BN coefficients, 1024 bias values
   if (d->taps == 9) pl.ok = pl.ok && d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN;
   else pl.ok = pl.ok && !d->want_stats && d->split == 0 &&
                ((d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_D2S && ((d->cout >> 2) % 32) == 0) ||

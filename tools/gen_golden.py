@@ -6,6 +6,7 @@ Nothing of the reference's source is copied: this script imports
   /root/reference/SOTAS/Lesions_Segment/YNet_2022.py   (UNet :509-602, get_model :496-507)
   /root/reference/Metrics/Region_based_metrics.py       (:3-61)
   /root/reference/Metrics/ConfusionMatrix_based_metrics.py (:4-63)
+  /root/reference/Metrics/PixelError_based_metrics.py (:3-37), Biomarker_based_metrics.py (:3-38)
 feeds them seeded inputs and writes inputs + outputs as small .npz fixtures under
 tests/golden/.  The loss head, optimizer and DDP do not exist in the reference
 (SURVEY.md §0); for those the fixture records what stock torch (the reference's own
@@ -31,6 +32,8 @@ sys.path.insert(0, os.path.join(REF, "Metrics"))
 import YNet_2022 as ref_ynet  # noqa: E402
 import Region_based_metrics as ref_region  # noqa: E402
 import ConfusionMatrix_based_metrics as ref_cm  # noqa: E402
+import PixelError_based_metrics as ref_px  # noqa: E402
+import Biomarker_based_metrics as ref_bio  # noqa: E402
 
 DICE_EPS = 1e-7
 
@@ -188,6 +191,10 @@ def metrics_cases():
         "cm.sensitivity": ref_cm.sensitivity,
         "cm.precision": ref_cm.precision,
         "cm.specificity": ref_cm.specificity,
+        "pixel.mean_squared_error": ref_px.mean_squared_error,          # PixelError_based_metrics.py:3-19
+        "pixel.root_mean_squared_error": ref_px.root_mean_squared_error,  # :21-37
+        "bio.thickness_difference": ref_bio.thickness_difference,      # Biomarker_based_metrics.py:3-21
+        "bio.vascularity_index": ref_bio.vascularity_index,            # :23-38
     }
     cases = {}
     cases["tiny_i64"] = (np.array([[1, 1, 0, 0], [1, 0, 0, 0]], dtype=np.int64),
