@@ -140,14 +140,19 @@ int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cout, int cin,
  * momentum=0.1, biased var to normalise, unbiased var into running_var).
  * ------------------------------------------------------------------------------------------ */
 /* partials [nblocks][2][c] -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale, and
- * running_mean/var update (skipped when running_mean == NULL).  count = N*H*W.                */
+ * running_mean/var update (skipped when running_mean == NULL).  count = N*H*W.
+ * conv_bias (may be NULL): bias of the conv in front of the BN (BioNet_2020.py:45-53, MGUNet_2021.py).
+ * The stored y excludes it -- in training mode it cancels in the BN output and its gradient is
+ * exactly zero -- so it only enters the running mean here and the eval-mode shift below.         */
 int oct_bn_finalize(const float* partials, int nblocks, int c, double count,
                     const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var,
-                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+                    float* mean, float* invstd, float* scale, float* shift, const float* conv_bias,
+                    void* stream);
 /* eval mode: scale/shift from the running statistics */
 int oct_bn_eval_coeffs(int c, const float* gamma, const float* beta, const float* running_mean,
-                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+                       const float* running_var, float eps, float* scale, float* shift,
+                       const float* conv_bias, void* stream);
 
 /* a = relu(y*scale+shift); p = maxpool2x2(a)  (nn.MaxPool2d(2,2), YNet_2022.py:516-522) */
 int oct_bn_relu_pool_fwd(int dtype, const void* y, const float* scale, const float* shift,

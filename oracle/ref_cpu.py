@@ -313,6 +313,101 @@ class OracleUNet:
             self.s[k] = self.s[k] - lr * gr
 
 
+class OracleBioUNet:
+    """`UNet` of SOTAS/Layers_Segment/BioNet_2020.py:24-75 restated on the primitives above: four
+    bias-conv blocks 64/128/256/512 with three poolings (:55-59), ConvTranspose + `cat([enc, dec])`
+    + block three times (:61-73), 1x1 `final` giving raw logits (:75).
+
+    PARITY UNPINNED against the reference for this topology: BioNet_2020.py imports torchvision,
+    which this image lacks, so the reference class cannot be run to make a fixture.  Every
+    primitive used here is pinned by the YNet_2022 fixtures; the wiring is checked against an
+    independent torch.nn restatement (oracle/torch_unet.TorchBioUNet) in tests/test_oracle.py."""
+
+    ENC = ["enc1", "enc2", "enc3", "enc4"]
+    DEC = [("up4", "dec4"), ("up3", "dec3"), ("up2", "dec2")]
+
+    def __init__(self, state, dtype=np.float64):
+        self.dtype = dtype
+        self.s = {k: (np.array(v, dtype=dtype) if np.issubdtype(np.asarray(v).dtype, np.floating)
+                      else np.array(v)) for k, v in state.items()}
+
+    def _block(self, x, mod, train, caches):
+        c = []
+        for ci, ni in ((0, 1), (3, 4)):
+            wk, cbk = f"{mod}.{ci}.weight", f"{mod}.{ci}.bias"
+            gk, bk = f"{mod}.{ni}.weight", f"{mod}.{ni}.bias"
+            rmk, rvk, nbk = f"{mod}.{ni}.running_mean", f"{mod}.{ni}.running_var", f"{mod}.{ni}.num_batches_tracked"
+            y = conv3x3_fwd(x, self.s[wk], self.s[cbk])
+            if train:
+                z, mean, var, invstd, xhat = bn_train_fwd(y, self.s[gk], self.s[bk])
+                n = y.shape[0] * y.shape[2] * y.shape[3]
+                self.s[rmk], self.s[rvk] = bn_running_update(self.s[rmk], self.s[rvk], mean, var, n)
+                self.s[nbk] = self.s[nbk] + 1
+            else:
+                z = bn_eval_fwd(y, self.s[gk], self.s[bk], self.s[rmk], self.s[rvk])
+                xhat = invstd = None
+            c.append((wk, cbk, gk, bk, x, xhat, invstd, z))
+            x = np.maximum(z, 0)
+        caches[mod] = c
+        return x
+
+    def forward(self, x, train=True):
+        x = np.asarray(x, dtype=self.dtype)
+        if x.shape[2] % 8 or x.shape[3] % 8:
+            raise RuntimeError("Sizes of tensors must match except in dimension 1")  # torch.cat, :64
+        caches, skips, pools = {}, [], []
+        h = x
+        for i, mod in enumerate(self.ENC):
+            h = self._block(h, mod, train, caches)
+            if i < 3:
+                skips.append(h)
+                a = h
+                h, idx = maxpool2x2_fwd(a)
+                pools.append((idx, a.shape))
+        ups = []
+        for di, (up, mod) in enumerate(self.DEC):
+            ups.append(h)
+            u = deconv2x2_fwd(h, self.s[f"{up}.weight"], self.s[f"{up}.bias"])
+            h = self._block(np.concatenate([skips[2 - di], u], axis=1), mod, train, caches)  # encoder first (:64)
+        logits = np.einsum("bchw,oc->bohw", h, self.s["final.weight"][:, :, 0, 0]) + self.s["final.bias"][None, :, None, None]
+        self._cache = (caches, pools, ups, h)
+        self.logits = logits
+        return logits
+
+    def backward(self, dlogits):
+        caches, pools, ups, hlast = self._cache
+        g = {}
+        g["final.weight"] = np.einsum("bohw,bchw->oc", dlogits, hlast)[:, :, None, None]
+        g["final.bias"] = dlogits.sum(axis=(0, 2, 3))
+        da = np.einsum("bohw,oc->bchw", dlogits, self.s["final.weight"][:, :, 0, 0])
+
+        def block_bwd(mod, da, need_dx=True):
+            for j, (wk, cbk, gk, bk, xin, xhat, invstd, z) in enumerate(reversed(caches[mod])):
+                dz = da * (z > 0)
+                dy, g[gk], g[bk] = bn_train_bwd(dz, xhat, self.s[gk], invstd)
+                g[cbk] = dy.sum(axis=(0, 2, 3))          # analytically zero (BN removes the mean)
+                da, g[wk] = conv3x3_bwd(xin, self.s[wk], dy, need_dx=(need_dx or j == 0))
+            return da
+
+        dskip = [None] * 3
+        for di in (2, 1, 0):
+            up, mod = self.DEC[di]
+            dcat = block_bwd(mod, da)
+            cs = dcat.shape[1] - self.s[f"{up}.weight"].shape[1]
+            dskip[2 - di], du = dcat[:, :cs], dcat[:, cs:]
+            da, g[f"{up}.weight"], g[f"{up}.bias"] = deconv2x2_bwd(ups[di], self.s[f"{up}.weight"], du)
+        dp = block_bwd("enc4", da)
+        for i in (2, 1, 0):
+            idx, shp = pools[i]
+            dp = block_bwd(self.ENC[i], maxpool2x2_bwd(dp, idx, shp) + dskip[i], need_dx=(i != 0))
+        return g
+
+    def loss_and_grads(self, x, target, w_ce=1.0, w_dice=0.0, dice_eps=1e-7):
+        logits = self.forward(x, train=True)
+        loss, ce, dice, cache = loss_head_fwd(logits, np.asarray(target), w_ce, w_dice, dice_eps)
+        return logits, (loss, ce, dice), self.backward(loss_head_bwd(cache, w_ce, w_dice, dice_eps))
+
+
 # --------------------------------------------------------------------------------------------
 # Metrics (reference: Metrics/Region_based_metrics.py, Metrics/ConfusionMatrix_based_metrics.py)
 # --------------------------------------------------------------------------------------------

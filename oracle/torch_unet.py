@@ -55,6 +55,41 @@ class TorchUNet(nn.Module):
         return torch.softmax(self.conv(x), dim=1)
 
 
+def _bio_stage(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
+                         nn.Conv2d(cout, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class TorchBioUNet(nn.Module):
+    """/root/reference/SOTAS/Layers_Segment/BioNet_2020.py:24-75 restated from its description
+    (the reference file itself is not importable here: it needs torchvision).  PARITY UNPINNED."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        widths = [64, 128, 256, 512]
+        cin = in_channels
+        for lvl, wd in enumerate(widths, start=1):
+            setattr(self, f"enc{lvl}", _bio_stage(cin, wd))
+            cin = wd
+        for lvl in (4, 3, 2):
+            wd = widths[lvl - 2]
+            setattr(self, f"up{lvl}", nn.ConvTranspose2d(2 * wd, wd, 2, stride=2))
+            setattr(self, f"dec{lvl}", _bio_stage(2 * wd, wd))
+        self.final = nn.Conv2d(64, out_channels, 1)
+        self.maxpool = nn.MaxPool2d(2)
+
+    def forward(self, x):
+        skips = []
+        for lvl in (1, 2, 3):
+            x = getattr(self, f"enc{lvl}")(x)
+            skips.append(x)
+            x = self.maxpool(x)
+        x = self.enc4(x)
+        for lvl in (4, 3, 2):
+            x = getattr(self, f"dec{lvl}")(torch.cat([skips[lvl - 2], getattr(self, f"up{lvl}")(x)], dim=1))
+        return self.final(x)
+
+
 def loss_fn(probs, target, w_ce=1.0, w_dice=0.0, eps=1e-7):
     ce = F.nll_loss(torch.log(probs), target)
     if w_dice == 0.0:

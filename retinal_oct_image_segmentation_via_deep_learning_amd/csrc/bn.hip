@@ -13,7 +13,7 @@
 __global__ void bn_finalize_kernel(const float* __restrict__ partials, int nblocks, int c, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_out,
-                                   float* invstd_out, float* scale, float* shift) {
+                                   float* invstd_out, float* scale, float* shift, const float* __restrict__ conv_bias) {
   const int ch = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
@@ -39,7 +39,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int nbloc
     shift[ch] = (float)((double)bt - mean * (double)g * invstd);
     if (running_mean) {
       const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-      running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mean);
+      // a conv bias in front of a train-mode BN cancels in the output; it only shifts the running mean
+      const double mb = mean + (conv_bias ? (double)conv_bias[ch] : 0.0);
+      running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mb);
       running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
     }
   }
@@ -48,29 +50,30 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int nbloc
 extern "C" int oct_bn_finalize(const float* partials, int nblocks, int c, double count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                               void* stream) {
+                               const float* conv_bias, void* stream) {
   OCT_CHECK(partials && gamma && beta && mean && invstd && scale && shift, "oct_bn_finalize: null pointer");
   OCT_CHECK(nblocks > 0 && c > 0 && count > 0, "oct_bn_finalize: bad sizes");
   OCT_CHECK((running_mean == nullptr) == (running_var == nullptr), "oct_bn_finalize: running stats mismatch");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(EW_THREADS), 0, as_stream(stream), partials, nblocks, c, count,
-                     gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                     gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, conv_bias);
   return oct_check_launch("bn_finalize");
 }
 
 __global__ void bn_eval_coeffs_kernel(int c, const float* gamma, const float* beta, const float* rm, const float* rv,
-                                      float eps, float* scale, float* shift) {
+                                      float eps, float* scale, float* shift, const float* conv_bias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < c) {
     const float sc = gamma[i] / sqrtf(rv[i] + eps);
     scale[i] = sc;
-    shift[i] = beta[i] - rm[i] * sc;
+    shift[i] = beta[i] - (rm[i] - (conv_bias ? conv_bias[i] : 0.f)) * sc;   // z = sc*(y + b - rm) + beta
   }
 }
 extern "C" int oct_bn_eval_coeffs(int c, const float* gamma, const float* beta, const float* running_mean,
-                                  const float* running_var, float eps, float* scale, float* shift, void* stream) {
+                                  const float* running_var, float eps, float* scale, float* shift,
+                                  const float* conv_bias, void* stream) {
   OCT_CHECK(c > 0 && gamma && beta && running_mean && running_var && scale && shift, "oct_bn_eval_coeffs: bad args");
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, as_stream(stream), c, gamma, beta,
-                     running_mean, running_var, eps, scale, shift);
+                     running_mean, running_var, eps, scale, shift, conv_bias);
   return oct_check_launch("bn_eval_coeffs");
 }
 

@@ -27,10 +27,66 @@ from . import _lib as L
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
-# (module attribute, layer-name prefix) in forward order -- YNet_2022.py:514-540
-ENC = [("encoder1", "enc1"), ("encoder2", "enc2"), ("encoder3", "enc3"), ("encoder4", "enc4")]
-BOTT = ("bottleneck", "bottleneck")
-DEC = [("decoder4", "dec4"), ("decoder3", "dec3"), ("decoder2", "dec2"), ("decoder1", "dec1")]
+@dataclass
+class ConvKeys:
+    """state_dict keys of one conv + BatchNorm pair"""
+    w: str
+    bn: str                 # prefix of .weight/.bias/.running_mean/.running_var/.num_batches_tracked
+    b: str | None = None    # conv bias (BioNet / MGUNet style blocks); None for bias=False
+
+
+@dataclass
+class BlockSpec:
+    name: str
+    c1: ConvKeys
+    c2: ConvKeys
+    cout: int
+
+
+@dataclass
+class NetSpec:
+    """Encoder-decoder topology shared by the reference's U-Nets.  `enc` ends with the bottleneck
+    (no pooling after it); `ups[i]` / `dec[i]` run in decode order and consume the skip of
+    enc[len(enc)-2-i]."""
+    cin: int
+    ncls: int
+    enc: list
+    ups: list               # (weight key, bias key, cout)
+    dec: list
+    head_w: str
+    head_b: str
+    dec_first: bool         # torch.cat((dec, enc), 1) [YNet_2022.py:557] vs cat([enc, dec]) [BioNet_2020.py:64]
+    softmax_out: bool       # UNet of YNet_2022 returns probabilities, BioNet's returns logits
+
+    @property
+    def divisor(self) -> int:
+        return 1 << (len(self.enc) - 1)
+
+    @property
+    def head_feat(self) -> int:
+        return self.dec[-1].cout
+
+
+def ynet_unet_spec(cin: int, ncls: int, f: int) -> NetSpec:
+    """UNet of SOTAS/{Lesions,Layers}_Segment/YNet_2022 (reference :509-602)."""
+    def blk(mod, pre, cout):
+        return BlockSpec(pre, ConvKeys(f"{mod}.{pre}conv1.weight", f"{mod}.{pre}norm1"),
+                         ConvKeys(f"{mod}.{pre}conv2.weight", f"{mod}.{pre}norm2"), cout)
+    enc = [blk(f"encoder{i + 1}", f"enc{i + 1}", f << i) for i in range(4)] + [blk("bottleneck", "bottleneck", f * 16)]
+    ups = [(f"upconv{k}.weight", f"upconv{k}.bias", f << (k - 1)) for k in (4, 3, 2, 1)]
+    dec = [blk(f"decoder{k}", f"dec{k}", f << (k - 1)) for k in (4, 3, 2, 1)]
+    return NetSpec(cin, ncls, enc, ups, dec, "conv.weight", "conv.bias", dec_first=True, softmax_out=True)
+
+
+def bionet_unet_spec(cin: int, ncls: int) -> NetSpec:
+    """UNet of SOTAS/Layers_Segment/BioNet_2020.py:24-75: three poolings, bias convs, cat([enc, dec]), logits."""
+    def blk(mod, cout):
+        return BlockSpec(mod, ConvKeys(f"{mod}.0.weight", f"{mod}.1", f"{mod}.0.bias"),
+                         ConvKeys(f"{mod}.3.weight", f"{mod}.4", f"{mod}.3.bias"), cout)
+    enc = [blk("enc1", 64), blk("enc2", 128), blk("enc3", 256), blk("enc4", 512)]
+    ups = [(f"up{k}.weight", f"up{k}.bias", c) for k, c in ((4, 256), (3, 128), (2, 64))]
+    dec = [blk("dec4", 256), blk("dec3", 128), blk("dec2", 64)]
+    return NetSpec(cin, ncls, enc, ups, dec, "final.weight", "final.bias", dec_first=False, softmax_out=False)
 
 
 def _stream() -> int:
@@ -66,6 +122,7 @@ class ConvRec:
     wkey: str
     gkey: str
     bkey: str
+    cbkey: str | None      # conv bias key (its gradient is exactly zero in front of a train-mode BN)
     src: Src
     y: torch.Tensor
     bn: BNState
@@ -80,8 +137,8 @@ class Ctx:
     n: int = 0
     h: int = 0
     w: int = 0
-    convs: dict = field(default_factory=dict)   # level -> [ConvRec conv1, ConvRec conv2]
-    ups: dict = field(default_factory=dict)     # k -> (input ConvRec, u tensor)
+    convs: dict = field(default_factory=dict)   # block name -> [ConvRec conv1, ConvRec conv2]
+    ups: dict = field(default_factory=dict)     # decode index -> (input ConvRec, u tensor)
     head_in: ConvRec | None = None
     target: torch.Tensor | None = None
     dice_coef: torch.Tensor | None = None
@@ -90,10 +147,12 @@ class Ctx:
 
 
 class UNetEngine:
-    def __init__(self, in_channels: int, out_channels: int, features: int, dtype: str = "bf16"):
+    def __init__(self, in_channels: int, out_channels: int, features: int = 32, dtype: str = "bf16",
+                 spec: NetSpec | None = None):
         if out_channels > L.MAX_CLASSES:
             raise L.OctError(f"out_channels={out_channels} exceeds the head kernel's limit {L.MAX_CLASSES}")
-        self.cin, self.ncls, self.f = in_channels, out_channels, features
+        self.spec = spec if spec is not None else ynet_unet_spec(in_channels, out_channels, features)
+        self.cin, self.ncls, self.f = self.spec.cin, self.spec.ncls, self.spec.head_feat
         self.set_dtype(dtype)
         self._packed = {}  # (key, mode) -> (version, tensor)
         self.debug = None  # set to a dict to capture intermediate gradients (tests / probes)
@@ -185,11 +244,11 @@ class UNetEngine:
                                          _stream()), "oct_unpack_wgrad")
 
     # ---- forward --------------------------------------------------------------------------------
-    def _conv_bn(self, P, mod, pre, i, src: Src, cout, n, h, w, train: bool, ctx: Ctx | None) -> ConvRec:
-        wkey = f"{mod}.{pre}conv{i}.weight"
-        nk = f"{mod}.{pre}norm{i}"
+    def _conv_bn(self, P, keys: ConvKeys, src: Src, cout, n, h, w, train: bool) -> ConvRec:
+        wkey, nk = keys.w, keys.bn
         wt = P[wkey]
         dev = wt.device
+        cbias = L.ptr(P[keys.b]) if keys.b else None
         wp = self._pack(wkey, wt, L.PACK_CONV_FPROP, cout, src.channels)
         y = self._act(n, h, w, cout, dev)
         scale = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -204,7 +263,7 @@ class UNetEngine:
                 partials.data_ptr(), nblk, cout, float(n * h * w), P[nk + ".weight"].data_ptr(),
                 P[nk + ".bias"].data_ptr(), BN_EPS, BN_MOMENTUM, P[nk + ".running_mean"].data_ptr(),
                 P[nk + ".running_var"].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
-                shift.data_ptr(), _stream()), "oct_bn_finalize")
+                shift.data_ptr(), cbias, _stream()), "oct_bn_finalize")
             P[nk + ".num_batches_tracked"].add_(1)
             bn = BNState(scale, shift, mean, invstd)
         else:
@@ -212,15 +271,14 @@ class UNetEngine:
             L.check(L.lib().oct_bn_eval_coeffs(
                 cout, P[nk + ".weight"].data_ptr(), P[nk + ".bias"].data_ptr(),
                 P[nk + ".running_mean"].data_ptr(), P[nk + ".running_var"].data_ptr(), BN_EPS,
-                scale.data_ptr(), shift.data_ptr(), _stream()), "oct_bn_eval_coeffs")
+                scale.data_ptr(), shift.data_ptr(), cbias, _stream()), "oct_bn_eval_coeffs")
             bn = BNState(scale, shift)
-        return ConvRec(wkey, nk + ".weight", nk + ".bias", src, y, bn, cout, n, h, w)
+        return ConvRec(wkey, nk + ".weight", nk + ".bias", keys.b, src, y, bn, cout, n, h, w)
 
-    def _block(self, P, level, names, src, cout, n, h, w, train, ctx):
-        mod, pre = names
-        r1 = self._conv_bn(P, mod, pre, 1, src, cout, n, h, w, train, ctx)
-        r2 = self._conv_bn(P, mod, pre, 2, Src(r1.y, cout, r1.bn), cout, n, h, w, train, ctx)
-        ctx.convs[level] = [r1, r2]
+    def _block(self, P, blk: BlockSpec, src, n, h, w, train, ctx):
+        r1 = self._conv_bn(P, blk.c1, src, blk.cout, n, h, w, train)
+        r2 = self._conv_bn(P, blk.c2, Src(r1.y, blk.cout, r1.bn), blk.cout, n, h, w, train)
+        ctx.convs[blk.name] = [r1, r2]
         return r2
 
     def forward(self, P: dict, x: torch.Tensor, train: bool, target: torch.Tensor | None = None,
@@ -231,11 +289,12 @@ class UNetEngine:
         if x.dim() != 4 or x.shape[1] != self.cin:
             raise RuntimeError(f"expected input (B,{self.cin},H,W), got {tuple(x.shape)}")
         n, _, h, w = x.shape
-        if h % 16 or w % 16:
-            # same failure the reference hits at torch.cat, YNet_2022.py:557
+        sp = self.spec
+        if h % sp.divisor or w % sp.divisor:
+            # same failure the reference hits at torch.cat (YNet_2022.py:557, BioNet_2020.py:64)
             raise RuntimeError(
-                f"Sizes of tensors must match except in dimension 1. Input {h}x{w} is not divisible by 16 "
-                "(four 2x2 poolings followed by four 2x up-samplings)")
+                f"Sizes of tensors must match except in dimension 1. Input {h}x{w} is not divisible by {sp.divisor} "
+                f"({len(sp.enc) - 1} 2x2 poolings followed by as many 2x up-samplings)")
         dev = x.device
         if dev.type != "cuda":
             raise L.OctError("the HIP path needs a device tensor (there is no CPU fallback)")
@@ -245,37 +304,35 @@ class UNetEngine:
         L.check(lib.oct_nchw_to_nhwc(self.dt, xf.data_ptr(), xt.data_ptr(), n, self.cin, h, w, _stream()),
                 "oct_nchw_to_nhwc")
         src = Src(xt, self.cin)
-        f = self.f
         hh, ww = h, w
-        skips = {}
-        for li, names in enumerate(ENC):
-            cout = f << li
-            r2 = self._block(P, names[1], names, src, cout, n, hh, ww, train, ctx)
-            skips[li + 1] = r2
-            pooled = self._act(n, hh // 2, ww // 2, cout, dev)
-            L.check(lib.oct_bn_relu_pool_fwd(self.dt, r2.y.data_ptr(), r2.bn.scale.data_ptr(),
-                                             r2.bn.shift.data_ptr(), pooled.data_ptr(), n, hh, ww, cout,
+        skips = []
+        prev = None
+        for li, blk in enumerate(sp.enc):
+            prev = self._block(P, blk, src, n, hh, ww, train, ctx)
+            if li == len(sp.enc) - 1:
+                break  # bottleneck: no pooling
+            skips.append(prev)
+            pooled = self._act(n, hh // 2, ww // 2, blk.cout, dev)
+            L.check(lib.oct_bn_relu_pool_fwd(self.dt, prev.y.data_ptr(), prev.bn.scale.data_ptr(),
+                                             prev.bn.shift.data_ptr(), pooled.data_ptr(), n, hh, ww, blk.cout,
                                              _stream()), "oct_bn_relu_pool_fwd")
             hh //= 2
             ww //= 2
-            src = Src(pooled, cout)
-        prev = self._block(P, "bott", BOTT, src, f * 16, n, hh, ww, train, ctx)
-        for di, names in enumerate(DEC):
-            k = 4 - di
-            cin_d, cout_d = prev.cout, prev.cout // 2
-            wkey = f"upconv{k}.weight"
+            src = Src(pooled, blk.cout)
+        for di, ((wkey, bkey, cout_d), blk) in enumerate(zip(sp.ups, sp.dec)):
+            cin_d = prev.cout
             wp = self._pack(wkey, P[wkey], L.PACK_DECONV_FPROP, cout_d, cin_d)
             u = self._act(n, hh * 2, ww * 2, cout_d, dev)
-            self._conv(Src(prev.y, cin_d, prev.bn), wp, 4 * cout_d, 1, n, hh, ww, u, out_mode=L.OUT_D2S,
-                       bias=P[f"upconv{k}.bias"])
-            ctx.ups[k] = (prev, u)
+            self._conv(Src(prev.y, cin_d, prev.bn), wp, 4 * cout_d, 1, n, hh, ww, u, out_mode=L.OUT_D2S, bias=P[bkey])
+            ctx.ups[di] = (prev, u)
             hh *= 2
             ww *= 2
-            sk = skips[k]
-            src = Src(u, cout_d, None, sk.y, sk.cout, sk.bn)
-            prev = self._block(P, names[1], names, src, cout_d, n, hh, ww, train, ctx)
+            sk = skips[len(skips) - 1 - di]
+            src = (Src(u, cout_d, None, sk.y, sk.cout, sk.bn) if sp.dec_first
+                   else Src(sk.y, sk.cout, sk.bn, u, cout_d, None))
+            prev = self._block(P, blk, src, n, hh, ww, train, ctx)
         ctx.head_in = prev
-        hd = L.HeadDesc(self.dt, n, h, w, f, self.ncls)
+        hd = L.HeadDesc(self.dt, n, h, w, self.f, self.ncls)
         probs = torch.empty((n, self.ncls, h, w), dtype=torch.float32, device=dev) if want_probs else None
         amax = torch.empty((n, h, w), dtype=torch.int64, device=dev) if want_argmax else None
         logits = torch.empty((n, self.ncls, h, w), dtype=torch.float32, device=dev) if want_logits else None
@@ -287,8 +344,8 @@ class UNetEngine:
             nb = lib.oct_head_blocks(C.byref(hd))
             partials = torch.empty((nb, L.HEAD_LOSS_SLOTS), dtype=torch.float64, device=dev)
         L.check(lib.oct_head_forward(C.byref(hd), prev.y.data_ptr(), prev.bn.scale.data_ptr(),
-                                     prev.bn.shift.data_ptr(), P["conv.weight"].data_ptr(),
-                                     P["conv.bias"].data_ptr(), L.ptr(target), L.ptr(probs), L.ptr(amax),
+                                     prev.bn.shift.data_ptr(), P[sp.head_w].data_ptr(),
+                                     P[sp.head_b].data_ptr(), L.ptr(target), L.ptr(probs), L.ptr(amax),
                                      L.ptr(logits), L.ptr(partials), _stream()), "oct_head_forward")
         if target is not None:
             w_ce, w_dice, eps = loss_cfg
@@ -353,8 +410,11 @@ class UNetEngine:
         self._conv(Src(dy, rec.cout), wp, cin, 9, n, h, w, d0, y1=d1, split=src.c0 if src.c1 else 0)
         return d0, d1
 
-    def _block_backward(self, level, da, dpool, G, accumulate, need_dx=True, partials=None):
-        r1, r2 = self._ctx.convs[level]
+    def _block_backward(self, name, da, dpool, G, accumulate, need_dx=True, partials=None):
+        r1, r2 = self._ctx.convs[name]
+        for r in (r1, r2):
+            if r.cbkey and not accumulate:
+                G[r.cbkey].zero_()   # a bias in front of a train-mode BatchNorm cancels in (y - mean): zero gradient
         dy2 = self._bn_backward(r2, da, dpool, G, accumulate, partials=partials)
         da1, _ = self._conv_backward(r2, dy2, G, accumulate)
         first_fused = (not need_dx and self.dtype == "bf16" and r1.src.channels == 1 and r1.src.bn0 is None
@@ -370,10 +430,13 @@ class UNetEngine:
         dy1 = self._bn_backward(r1, da1, None, G, accumulate)
         return self._conv_backward(r1, dy1, G, accumulate, need_dx=need_dx)
 
-    def backward(self, P: dict, ctx: Ctx, G: dict, dprobs: torch.Tensor | None = None, accumulate=False):
+    def backward(self, P: dict, ctx: Ctx, G: dict, dprobs: torch.Tensor | None = None, accumulate=False,
+                 dlogits: torch.Tensor | None = None):
         """Fills G (name -> fp32 grad tensor, torch layout) for every parameter.
-        dprobs=None: gradient of the fused loss recorded by forward(target=...)."""
+        dprobs: gradient wrt the softmax output; dlogits: gradient wrt the logits (BioNet-style nets);
+        neither: gradient of the fused loss recorded by forward(target=...)."""
         lib = L.lib()
+        sp = self.spec
         self._P, self._ctx = P, ctx
         n, h, w, f, ncls = ctx.n, ctx.h, ctx.w, self.f, self.ncls
         rec = ctx.head_in
@@ -383,14 +446,15 @@ class UNetEngine:
         if dprobs is not None:
             dprobs = dprobs.to(torch.float32).contiguous()
             tgt, dc, w_ce = None, None, 0.0
-        else:
+        elif dlogits is None:
             if ctx.target is None:
-                raise RuntimeError("backward without dprobs needs forward(target=...)")
+                raise RuntimeError("backward without an output gradient needs forward(target=...)")
             tgt, dc, w_ce = ctx.target, ctx.dice_coef, ctx.loss_cfg[0]
         hsrc = Src(rec.y, f, rec.bn)
         head_partials = None
-        bgrad = G["conv.bias"]
-        if f == 32:
+        hw, hb = P[sp.head_w], P[sp.head_b]
+        bgrad = G[sp.head_b]
+        if f == 32 and dlogits is None:
             # fused: dlogits + dA = W^T dlogits + bias gradient + BN-backward partial sums in one pass over y
             if not accumulate:
                 bgrad.zero_()
@@ -399,42 +463,50 @@ class UNetEngine:
             head_partials = torch.empty((nb, 2, f), dtype=torch.float32, device=dev)
             L.check(lib.oct_head_backward_fused(
                 C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(), rec.bn.shift.data_ptr(),
-                rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(), P["conv.weight"].data_ptr(),
-                P["conv.bias"].data_ptr(), L.ptr(tgt), L.ptr(dc), w_ce, L.ptr(dprobs), dl.data_ptr(), da.data_ptr(),
+                rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(), hw.data_ptr(),
+                hb.data_ptr(), L.ptr(tgt), L.ptr(dc), w_ce, L.ptr(dprobs), dl.data_ptr(), da.data_ptr(),
                 head_partials.data_ptr(), bgrad.data_ptr(), _stream()), "oct_head_backward_fused")
         else:
-            L.check(lib.oct_head_dlogits(C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
-                                         rec.bn.shift.data_ptr(), P["conv.weight"].data_ptr(),
-                                         P["conv.bias"].data_ptr(), L.ptr(tgt), L.ptr(dc), w_ce, L.ptr(dprobs),
-                                         dl.data_ptr(), _stream()), "oct_head_dlogits")
+            if dlogits is not None:
+                dlf = dlogits.to(torch.float32).contiguous()
+                L.check(lib.oct_nchw_to_nhwc(self.dt, dlf.data_ptr(), dl.data_ptr(), n, ncls, h, w, _stream()),
+                        "oct_nchw_to_nhwc")
+            else:
+                L.check(lib.oct_head_dlogits(C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
+                                             rec.bn.shift.data_ptr(), hw.data_ptr(), hb.data_ptr(), L.ptr(tgt),
+                                             L.ptr(dc), w_ce, L.ptr(dprobs), dl.data_ptr(), _stream()),
+                        "oct_head_dlogits")
             L.check(lib.oct_channel_sum(self.dt, dl.data_ptr(), bgrad.data_ptr(), n * h * w, ncls, int(accumulate),
                                         _stream()), "oct_channel_sum")
-            wp = self._pack("conv.weight", P["conv.weight"], L.PACK_1X1_DGRAD, ncls, f)
+            wp = self._pack(sp.head_w, hw, L.PACK_1X1_DGRAD, ncls, f)
             da = self._act(n, h, w, f, dev)
             self._conv(Src(dl, ncls), wp, f, 1, n, h, w, da)
         # head weight gradient through the generic 1x1 wgrad
         dwp = self._wgrad(hsrc, dl, ncls, 1, n, h, w)
-        self._unpack(L.PACK_1X1_FPROP, dwp, G["conv.weight"], ncls, f, accumulate)
-        dskip = {}
-        for di in range(4):  # dec1, dec2, dec3, dec4
-            k = di + 1
-            du, dskip[k] = self._block_backward(f"dec{k}", da, None, G, accumulate,
-                                                partials=head_partials if k == 1 else None)
-            prev, u = ctx.ups[k]
-            cin_d, cout_d = prev.cout, prev.cout // 2
+        self._unpack(L.PACK_1X1_FPROP, dwp, G[sp.head_w], ncls, f, accumulate)
+        nd = len(sp.dec)
+        dskip = [None] * nd
+        for di in range(nd - 1, -1, -1):   # last decoder block first
+            d0, d1 = self._block_backward(sp.dec[di].name, da, None, G, accumulate,
+                                          partials=head_partials if di == nd - 1 else None)
+            du, dskip[di] = (d0, d1) if sp.dec_first else (d1, d0)
+            wkey, bkey, cout_d = sp.ups[di]
+            prev, u = ctx.ups[di]
+            cin_d = prev.cout
             hl, wl = prev.h, prev.w
-            bgrad = G[f"upconv{k}.bias"]
+            bgrad = G[bkey]
             if not accumulate:
                 bgrad.zero_()
             dwp = self._wgrad(Src(prev.y, cin_d, prev.bn), du, 4 * cout_d, 1, n, hl, wl, dy_mode=L.IN_S2D,
                               dbias=bgrad)
-            self._unpack(L.PACK_DECONV_FPROP, dwp, G[f"upconv{k}.weight"], cout_d, cin_d, accumulate)
-            wkey = f"upconv{k}.weight"
+            self._unpack(L.PACK_DECONV_FPROP, dwp, G[wkey], cout_d, cin_d, accumulate)
             wp = self._pack(wkey, P[wkey], L.PACK_DECONV_DGRAD, cout_d, cin_d)
             da = self._act(n, hl, wl, cin_d, dev)
             self._conv(Src(du, cout_d), wp, cin_d, 1, n, hl, wl, da, in_mode=L.IN_S2D)
-        dpool, _ = self._block_backward("bott", da, None, G, accumulate)
-        for k in (4, 3, 2, 1):
-            dpool, _ = self._block_backward(f"enc{k}", dskip[k], dpool, G, accumulate, need_dx=(k != 1))
+        dpool, _ = self._block_backward(sp.enc[-1].name, da, None, G, accumulate)
+        for li in range(len(sp.enc) - 2, -1, -1):
+            # the skip of enc[li] was consumed by decode step nd-1-li
+            dpool, _ = self._block_backward(sp.enc[li].name, dskip[nd - 1 - li], dpool, G, accumulate,
+                                            need_dx=(li != 0))
         self._P = self._ctx = None
         return G

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import UNetEngine
+from .engine import UNetEngine, bionet_unet_spec
 
 
 def _block(cin: int, cout: int, name: str) -> nn.Sequential:
@@ -34,43 +34,39 @@ class _UNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, *params):
-        ectx, probs, _, _ = model._engine.forward(model._tensors(), x, train=True)
-        ctx.model, ctx.ectx = model, ectx
-        return probs
+        out = model._run(x, train=True, keep_ctx=ctx)
+        ctx.model = model
+        return out
 
     @staticmethod
-    def backward(ctx, dprobs):
+    def backward(ctx, dout):
         model = ctx.model
         names = [n for n, _ in model.named_parameters()]
         P = model._tensors()
         G = {n: torch.empty_like(P[n]) for n in names}
-        model._engine.backward(P, ctx.ectx, G, dprobs=dprobs)
+        if model._engine.spec.softmax_out:
+            model._engine.backward(P, ctx.ectx, G, dprobs=dout)
+        else:
+            model._engine.backward(P, ctx.ectx, G, dlogits=dout)
         ctx.ectx = None
         return (None, None) + tuple(G[n] for n in names)
 
 
-class UNet(nn.Module):
-    def __init__(self, in_channels=3, out_channels=1, init_features=32, compute_dtype="bf16"):
-        super().__init__()
-        f = init_features
-        self.encoder1 = _block(in_channels, f, "enc1")
-        self.pool1 = nn.MaxPool2d(kernel_size=2, stride=2)
-        self.encoder2 = _block(f, f * 2, "enc2")
-        self.pool2 = nn.MaxPool2d(kernel_size=2, stride=2)
-        self.encoder3 = _block(f * 2, f * 4, "enc3")
-        self.pool3 = nn.MaxPool2d(kernel_size=2, stride=2)
-        self.encoder4 = _block(f * 4, f * 8, "enc4")
-        self.pool4 = nn.MaxPool2d(kernel_size=2, stride=2)
-        self.bottleneck = _block(f * 8, f * 16, "bottleneck")
-        for k, mult in ((4, 8), (3, 4), (2, 2), (1, 1)):
-            setattr(self, f"upconv{k}", nn.ConvTranspose2d(f * mult * 2, f * mult, kernel_size=2, stride=2))
-            setattr(self, f"decoder{k}", _block(f * mult * 2, f * mult, f"dec{k}"))
-        self.conv = nn.Conv2d(f, out_channels, kernel_size=1)
-        self.softmax = nn.Softmax2d()
-        self._engine = UNetEngine(in_channels, out_channels, f, compute_dtype)
+class _EngineNet(nn.Module):
+    """Shared host logic of the engine-backed networks; subclasses build the parameter containers
+    (in the reference's construction order) and set `self._engine`."""
+
+    def _run(self, x, train: bool, keep_ctx=None):
+        """The reference forward's return value: probabilities (YNet_2022 UNet) or logits (BioNet UNet)."""
+        soft = self._engine.spec.softmax_out
+        ectx, probs, _, lg = self._engine.forward(self._tensors(), x, train=train, want_probs=soft,
+                                                  want_logits=not soft)
+        if keep_ctx is not None:
+            keep_ctx.ectx = ectx
+        return probs if soft else lg
 
     # ---- configuration --------------------------------------------------------------------------
-    def set_compute_dtype(self, dtype: str) -> "UNet":
+    def set_compute_dtype(self, dtype: str):
         """'bf16' (production) or 'f32' (parity mode: same kernels, fp32 storage, exact fp32 MFMA)."""
         self._engine.set_dtype(dtype)
         return self
@@ -92,8 +88,7 @@ class UNet(nn.Module):
         needs_grad = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
         if needs_grad:
             return _UNetFn.apply(self, x, *self.parameters())
-        _, probs, _, _ = self._engine.forward(self._tensors(), x, train=self.training)
-        return probs
+        return self._run(x, train=self.training)
 
     # ---- fused extras (not in the reference) --------------------------------------
     @torch.no_grad()
@@ -133,6 +128,60 @@ class UNet(nn.Module):
         _, _, _, lg = self._engine.forward(self._tensors(), x, train=self.training, want_probs=False,
                                            want_logits=True)
         return lg
+
+
+class UNet(_EngineNet):
+    """SOTAS/{Lesions,Layers}_Segment/YNet_2022 `UNet` (reference :509-602)."""
+
+    def __init__(self, in_channels=3, out_channels=1, init_features=32, compute_dtype="bf16"):
+        super().__init__()
+        f = init_features
+        self.encoder1 = _block(in_channels, f, "enc1")
+        self.pool1 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.encoder2 = _block(f, f * 2, "enc2")
+        self.pool2 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.encoder3 = _block(f * 2, f * 4, "enc3")
+        self.pool3 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.encoder4 = _block(f * 4, f * 8, "enc4")
+        self.pool4 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.bottleneck = _block(f * 8, f * 16, "bottleneck")
+        for k, mult in ((4, 8), (3, 4), (2, 2), (1, 1)):
+            setattr(self, f"upconv{k}", nn.ConvTranspose2d(f * mult * 2, f * mult, kernel_size=2, stride=2))
+            setattr(self, f"decoder{k}", _block(f * mult * 2, f * mult, f"dec{k}"))
+        self.conv = nn.Conv2d(f, out_channels, kernel_size=1)
+        self.softmax = nn.Softmax2d()
+        self._engine = UNetEngine(in_channels, out_channels, f, compute_dtype)
+
+
+def _bias_block(cin: int, cout: int) -> nn.Sequential:
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
+                         nn.Conv2d(cout, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class BioUNet(_EngineNet):
+    """`UNet` of SOTAS/Layers_Segment/BioNet_2020.py:24-75 (BASELINE cfg1 is `UNet(1, 2)`): widths
+    64..512, three poolings, bias convolutions, `cat([enc, dec])`, raw logits out.  Same
+    constructor arguments, construction order (seeded init matches) and 106 state_dict keys."""
+
+    def __init__(self, in_channels, out_channels, compute_dtype="bf16"):
+        super().__init__()
+        self.enc1 = _bias_block(in_channels, 64)
+        self.enc2 = _bias_block(64, 128)
+        self.enc3 = _bias_block(128, 256)
+        self.enc4 = _bias_block(256, 512)
+        self.up4 = nn.ConvTranspose2d(512, 256, kernel_size=2, stride=2)
+        self.dec4 = _bias_block(512, 256)
+        self.up3 = nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2)
+        self.dec3 = _bias_block(256, 128)
+        self.up2 = nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2)
+        self.dec2 = _bias_block(128, 64)
+        self.final = nn.Conv2d(64, out_channels, kernel_size=1)
+        self.maxpool = nn.MaxPool2d(2)
+        self._engine = UNetEngine(in_channels, out_channels, dtype=compute_dtype,
+                                  spec=bionet_unet_spec(in_channels, out_channels))
+
+    def conv_block(self, in_ch, out_ch):
+        return _bias_block(in_ch, out_ch)
 
 
 def get_model(model_name, in_channels=1, num_classes=9, ratio=0.5):

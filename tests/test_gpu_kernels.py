@@ -231,7 +231,7 @@ def test_bn_forward_pool_backward(env, dt, shape):
     partd, gammad, betad = fdev(part), fdev(gamma), fdev(beta)  # keep alive: raw pointers below
     L.check(lib.oct_bn_finalize(partd.data_ptr(), 2, c, float(n * h * w), gammad.data_ptr(),
                                 betad.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), mean.data_ptr(),
-                                invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), st))
+                                invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, st))
     z, rmean, rvar, rinv, xhat = O.bn_train_fwd(y64, gamma.astype(np.float64), beta.astype(np.float64))
     close(mean.cpu().numpy(), rmean, "f32", "mean", scale_tol=1e-5)
     close(invstd.cpu().numpy(), rinv, "f32", "invstd", scale_tol=1e-5)

@@ -102,3 +102,46 @@ def test_metrics_seeded_full_size(golden_dir):
     assert [int(c["tp"]), int(c["t"]), int(c["p"]), c["n"]] == z["seeded_counts"].tolist()
     for fname, fn in ref_cpu.METRIC_FUNCS.items():
         np.testing.assert_allclose(fn(a, b), z[f"out/seeded_32x512x1024/{fname}"], rtol=1e-13)
+
+
+def _bio_case(seed, n, cin, ncls, h, w):
+    """Seeded BioNet-UNet case (weights, input, labels).  Parity unpinned: see OracleBioUNet."""
+    import torch
+    from oracle.torch_unet import TorchBioUNet
+    torch.manual_seed(seed)
+    m = TorchBioUNet(cin, ncls).double().train()
+    with torch.no_grad():   # non-trivial BN affine parameters and conv biases
+        for k, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+    t = torch.randint(0, ncls, (n, h, w), generator=g)
+    return m, x, t
+
+
+def test_bionet_unet_oracle_matches_torch_restatement():
+    import torch
+    import torch.nn.functional as F
+    m, x, t = _bio_case(11, 2, 1, 2, 16, 24)
+    state0 = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    logits = m(x)
+    F.cross_entropy(logits, t).backward()
+    o = ref_cpu.OracleBioUNet(state0)
+    ol, (loss, ce, dice), g = o.loss_and_grads(x.numpy(), t.numpy())
+    np.testing.assert_allclose(ol, logits.detach().numpy(), rtol=1e-9, atol=1e-9)
+    assert abs(ce - F.cross_entropy(logits, t).item()) < 1e-10
+    for k, p in m.named_parameters():
+        ref = p.grad.numpy()
+        tol = 1e-9 * max(1.0, np.abs(ref).max())
+        if k.endswith((".0.bias", ".3.bias")):          # conv bias in front of BN: zero up to rounding
+            assert np.abs(g[k]).max() < 1e-9 and np.abs(ref).max() < 1e-9
+        else:
+            np.testing.assert_allclose(g[k], ref, rtol=1e-7, atol=tol, err_msg=k)
+    for k, v in m.state_dict().items():                # running statistics (conv bias enters the mean)
+        if "running" in k:
+            np.testing.assert_allclose(o.s[k], v.numpy(), rtol=1e-10, atol=1e-12, err_msg=k)
+    m.eval()
+    np.testing.assert_allclose(o.forward(x.numpy(), train=False), m(x).detach().numpy(), rtol=1e-9, atol=1e-9)
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        o.forward(np.zeros((1, 1, 20, 16)))
