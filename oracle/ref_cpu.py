@@ -318,10 +318,9 @@ class OracleBioUNet:
     bias-conv blocks 64/128/256/512 with three poolings (:55-59), ConvTranspose + `cat([enc, dec])`
     + block three times (:61-73), 1x1 `final` giving raw logits (:75).
 
-    PARITY UNPINNED against the reference for this topology: BioNet_2020.py imports torchvision,
-    which this image lacks, so the reference class cannot be run to make a fixture.  Every
-    primitive used here is pinned by the YNet_2022 fixtures; the wiring is checked against an
-    independent torch.nn restatement (oracle/torch_unet.TorchBioUNet) in tests/test_oracle.py."""
+    Pinned by tests/golden/bionet_unet_*.npz, produced by the reference's own class
+    (tools/gen_golden_bionet.py), and cross-checked against an independent torch.nn restatement
+    (oracle/torch_unet.TorchBioUNet) in tests/test_oracle.py."""
 
     ENC = ["enc1", "enc2", "enc3", "enc4"]
     DEC = [("up4", "dec4"), ("up3", "dec3"), ("up2", "dec2")]

@@ -62,7 +62,8 @@ def _bio_stage(cin, cout):
 
 class TorchBioUNet(nn.Module):
     """/root/reference/SOTAS/Layers_Segment/BioNet_2020.py:24-75 restated from its description
-    (the reference file itself is not importable here: it needs torchvision).  PARITY UNPINNED."""
+    (same module names and construction order, hence the same state_dict and seeded init); pinned
+    by tests/golden/bionet_unet_*.npz, which tools/gen_golden_bionet.py made from the reference class."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()

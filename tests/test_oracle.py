@@ -104,20 +104,46 @@ def test_metrics_seeded_full_size(golden_dir):
         np.testing.assert_allclose(fn(a, b), z[f"out/seeded_32x512x1024/{fname}"], rtol=1e-13)
 
 
+BIO_CASES = ["bionet_unet_c2_2x16x24", "bionet_unet_in3_c4_1x32x16"]
+
+
 def _bio_case(seed, n, cin, ncls, h, w):
-    """Seeded BioNet-UNet case (weights, input, labels).  Parity unpinned: see OracleBioUNet."""
-    import torch
+    """Seeded BioNet-UNet case on the torch restatement, float64."""
+    from oracle.cases import bio_case
     from oracle.torch_unet import TorchBioUNet
-    torch.manual_seed(seed)
-    m = TorchBioUNet(cin, ncls).double().train()
-    with torch.no_grad():   # non-trivial BN affine parameters and conv biases
-        for k, p in m.named_parameters():
-            if p.dim() == 1:
-                p.add_(0.2 * torch.randn_like(p))
-    g = torch.Generator().manual_seed(seed + 1)
-    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
-    t = torch.randint(0, ncls, (n, h, w), generator=g)
-    return m, x, t
+    m, x, t = bio_case(TorchBioUNet, seed, n, cin, ncls, h, w)
+    return m.double(), x.double(), t
+
+
+@pytest.mark.parametrize("name", BIO_CASES)
+def test_bionet_unet_oracle_matches_reference_fixture(golden_dir, name):
+    """OracleBioUNet and TorchBioUNet against vectors produced by the reference's own class
+    (tools/gen_golden_bionet.py): weights rebuilt from the seed must carry the reference's
+    checksums, then logits / loss / gradients / running stats / eval logits must agree."""
+    import torch
+    from oracle.cases import bio_grad_errors, bio_weights_match
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    seed, n, cin, ncls, h, w = (int(v) for v in z["meta"])
+    w_ce, w_dice, eps = (float(v) for v in z["hyper"])
+    from oracle.cases import bio_case
+    from oracle.torch_unet import TorchBioUNet
+    m, x, t = bio_case(TorchBioUNet, seed, n, cin, ncls, h, w)
+    assert bio_weights_match(z, m.state_dict())
+    assert np.array_equal(x.numpy(), z["x"]) and np.array_equal(t.numpy(), z["target"])
+    o = ref_cpu.OracleBioUNet({k: v.numpy() for k, v in m.state_dict().items()})
+    logits, (loss, ce, dice), g = o.loss_and_grads(z["x"], z["target"], w_ce, w_dice, eps)
+    np.testing.assert_allclose(logits, z["logits"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose([loss, ce, dice], z["loss"], rtol=1e-10)
+    assert bio_grad_errors(z, g, 1e-7) == []
+    for k in z.files:
+        if k.startswith("b1/") and "running" in k:
+            np.testing.assert_allclose(o.s[k[3:]], z[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(o.forward(z["x"], train=False), z["logits_eval"], rtol=1e-9, atol=1e-9)
+    # the torch restatement (CPU baseline / bf16 comparisons) is the same function
+    md = m.double()
+    np.testing.assert_allclose(md(x.double()).detach().numpy(), z["logits"], rtol=1e-9, atol=1e-9)
+    api = np.load(os.path.join(golden_dir, "bionet_api.npz"))
+    assert int(api["n_params"]) == 7701890 and "Sizes of tensors must match" in str(api["negative_msg"])
 
 
 def test_bionet_unet_oracle_matches_torch_restatement():
