@@ -241,6 +241,46 @@ int oct_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float
                  float weight_decay, float grad_scale, int first, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Building blocks of the reference's other U-Net families; NHWC tensors
+ * of `dtype`, materialised activations.
+ * ------------------------------------------------------------------------------------------ */
+#define OCT_ACT_NONE 0
+#define OCT_ACT_RELU 1
+#define OCT_ACT_SIGMOID 2
+/* out = act(y*scale[c] + shift[c] (+ res)).  Covers BN+ReLU (MGUNet_2021.py:46-55), conv bias
+ * without BN (scale=1, shift=bias; MGUNet_2021.py:57-64, common.py:9), the residual sum
+ * `conv(x) + init_conv` + act (common.py:21-25), BN+Sigmoid (common.py:77-81).  res may be NULL. */
+int oct_affine_act_fwd(int dtype, const void* y, const float* scale, const float* shift,
+                       const void* res, int act, void* out, size_t npix, int c, void* stream);
+/* dz = dout * act'(z), from the stored output: relu [out>0], sigmoid out*(1-out). dz may alias dout */
+int oct_act_bwd(int dtype, const void* dout, const void* out, int act, void* dz, size_t n, void* stream);
+/* nn.MaxPool2d(k) on a materialised activation (SD_Layer_Net/unet.py:85, MGUNet_2021.py:211-217);
+ * h, w must be multiples of k.  Backward writes all of da: dout to the first maximum of each
+ * window in row-major order (ATen's tie rule), zero elsewhere.                                  */
+int oct_maxpool_fwd(int dtype, const void* a, void* out, int n, int h, int w, int c, int k, void* stream);
+int oct_maxpool_bwd(int dtype, const void* a, const void* dout, void* da, int n, int h, int w, int c,
+                    int k, void* stream);
+/* nn.Upsample(scale_factor=f, mode="bilinear", align_corners=True) / nn.UpsamplingBilinear2d
+ * (common.py:31, MGUNet_2021.py:79,98): x (n,h,w,c) -> out (n,h*f,w*f,c); backward is the exact
+ * transpose (dout at h*f x w*f -> dx at h x w), deterministic (gather, no atomics).             */
+int oct_bilinear_up_fwd(int dtype, const void* x, void* out, int n, int h, int w, int c, int factor,
+                        void* stream);
+int oct_bilinear_up_bwd(int dtype, const void* dout, void* dx, int n, int h, int w, int c, int factor,
+                        void* stream);
+/* Scatter step of nn.ConvTranspose2d(kernel=s, stride=s) (MGUNet_2021.py:95, s=4): the GEMM output
+ * in[n,h,w,(dy*s+dx)*cout+co] goes to out[n,h*s+dy,w*s+dx,co] (+ bias[co], may be NULL);
+ * space_to_depth is its inverse, used on dOut before the weight / data gradients.               */
+int oct_depth_to_space(int dtype, const void* in, const float* bias, void* out, int n, int h, int w,
+                       int cout, int s, void* stream);
+int oct_space_to_depth(int dtype, const void* in, void* out, int n, int h, int w, int cout, int s,
+                       void* stream);
+/* Attention gate product `x * psi` (SD_Layer_Net/common.py:91): out[pix,c] = x[pix,c]*p[pix];
+ * backward dx = dout*p, dp[pix] = sum_c dout*x.                                                 */
+int oct_gate_fwd(int dtype, const void* x, const void* p, void* out, size_t npix, int c, void* stream);
+int oct_gate_bwd(int dtype, const void* dout, const void* x, const void* p, void* dx, void* dp,
+                 size_t npix, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Metrics (Metrics/Region_based_metrics.py:3-61, Metrics/ConfusionMatrix_based_metrics.py:4-63)
  * One pass over the two masks; integer inputs are reduced exactly in 64-bit with numpy's
  * same-dtype product semantics, float inputs in fp64.

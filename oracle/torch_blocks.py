@@ -1,0 +1,120 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY): the reference's other block families restated on stock
+torch.nn, from their description -- same sub-module names, hence the same state_dict keys and
+seeded default init:
+  /root/reference/SOTAS/Layers_Segment/MGUNet_2021.py:42-108     UnetConv, UnetUp, UnetUp4
+  /root/reference/SOTAS/Layers_Segment/SD_Layer_Net/common.py:6-41,64-91   conv_block, up_conv, Attention_block
+  /root/reference/SOTAS/Layers_Segment/SD_Layer_Net/unet.py:8-150          U_Net, AttU_Net
+Pinned by tests/test_oracle_blocks.py against fixtures generated from the reference classes
+(tools/gen_golden_blocks.py).  Only tests/ may import this file.
+"""
+import torch
+import torch.nn as nn
+
+
+def _cbr(cin, cout, bn):
+    mods = [nn.Conv2d(cin, cout, 3, 1, 1)] + ([nn.BatchNorm2d(cout)] if bn else []) + [nn.ReLU(inplace=True)]
+    return nn.Sequential(*mods)
+
+
+class UnetConv(nn.Module):
+    def __init__(self, in_channels, out_channels, is_batchnorm=True):
+        super().__init__()
+        self.conv1 = _cbr(in_channels, out_channels, is_batchnorm)
+        self.conv2 = _cbr(out_channels, out_channels, is_batchnorm)
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x))
+
+
+class UnetUp(nn.Module):
+    K = 2
+
+    def __init__(self, in_channels, out_channels, is_deconv=True):
+        super().__init__()
+        if is_deconv:
+            self.up = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=self.K, stride=self.K)
+        else:
+            self.up = nn.Sequential(nn.UpsamplingBilinear2d(scale_factor=self.K), nn.Conv2d(in_channels, out_channels, 1))
+        self.conv = UnetConv(in_channels, out_channels, True)
+
+    def forward(self, x1, x2):
+        return self.conv(torch.cat([x2, self.up(x1)], dim=1))
+
+
+class UnetUp4(UnetUp):
+    K = 4
+
+
+class conv_block(nn.Module):
+    def __init__(self, ch_in, ch_out):
+        super().__init__()
+        self.init_conv = nn.Conv2d(ch_in, ch_out, 3, 1, 1)
+        self.conv = nn.Sequential(nn.Conv2d(ch_out, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), nn.Dropout2d(0.0),
+                                  nn.ReLU(), nn.Conv2d(ch_out, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), nn.Dropout2d(0.0))
+        self.activation = nn.ReLU()
+
+    def forward(self, x):
+        i = self.init_conv(x)
+        return self.activation(self.conv(i) + i)
+
+
+class up_conv(nn.Module):
+    def __init__(self, ch_in, ch_out, scale_factor=2):
+        super().__init__()
+        self.up = nn.Sequential(nn.Upsample(scale_factor=scale_factor, mode="bilinear", align_corners=True),
+                                nn.Conv2d(ch_in, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), nn.Dropout2d(0.0), nn.ReLU())
+
+    def forward(self, x):
+        return self.up(x)
+
+
+class Attention_block(nn.Module):
+    def __init__(self, channels_g, channels_x, F_int):
+        super().__init__()
+        self.W_g = nn.Sequential(nn.Conv2d(channels_g, F_int, 1), nn.BatchNorm2d(F_int))
+        self.W_x = nn.Sequential(nn.Conv2d(channels_x, F_int, 1), nn.BatchNorm2d(F_int))
+        self.psi = nn.Sequential(nn.Conv2d(F_int, 1, 1), nn.BatchNorm2d(1), nn.Sigmoid())
+        self.relu = nn.ReLU()
+
+    def forward(self, g, x):
+        return x * self.psi(self.relu(self.W_g(g) + self.W_x(x)))
+
+
+class _SDNet(nn.Module):
+    def __init__(self, img_ch, output_ch, channels, gates, head_in):
+        super().__init__()
+        self.Maxpool = nn.MaxPool2d(2, 2)
+        self.Conv1 = conv_block(img_ch, channels[0])
+        for i in range(1, 5):
+            setattr(self, f"Conv{i + 1}", conv_block(channels[i - 1], channels[i]))
+        for i in (5, 4, 3, 2):
+            setattr(self, f"Up{i}", up_conv(channels[i - 1], channels[i - 2]))
+            if gates:
+                setattr(self, f"Att{i}", Attention_block(channels[i - 2], channels[i - 2], channels[i - 2] // 2))
+            setattr(self, f"Up_conv{i}", conv_block(channels[i - 1], channels[i - 2]))
+        self.Conv_1x1 = nn.Conv2d(head_in, output_ch, 1)
+        self._gates = gates
+
+    def forward(self, x):
+        feats = []
+        for i in range(1, 6):
+            x = getattr(self, f"Conv{i}")(x if i == 1 else self.Maxpool(x))
+            feats.append(x)
+        d = feats[-1]
+        for i in (5, 4, 3, 2):
+            d = getattr(self, f"Up{i}")(d)
+            skip = feats[i - 2]
+            if self._gates:
+                skip = getattr(self, f"Att{i}")(d, skip)
+            d = getattr(self, f"Up_conv{i}")(torch.cat((skip, d), dim=1))
+        return self.Conv_1x1(d)
+
+
+class U_Net(_SDNet):
+    def __init__(self, img_ch=3, output_ch=1, channels=(64, 128, 256, 512, 1024)):
+        super().__init__(img_ch, output_ch, list(channels), False, 64)
+
+
+class AttU_Net(_SDNet):
+    def __init__(self, img_ch=1, output_ch=1, channels=(64, 128, 256, 512, 1024)):
+        super().__init__(img_ch, output_ch, list(channels), True, channels[0])

@@ -17,6 +17,7 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 DT_BF16, DT_F32 = 0, 1
 XF_NONE, XF_AFFINE_RELU = 0, 1
 IN_PLAIN, IN_S2D = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 OUT_PLAIN, OUT_D2S = 0, 1
 PACK_CONV_FPROP, PACK_CONV_DGRAD, PACK_DECONV_FPROP, PACK_DECONV_DGRAD, PACK_1X1_DGRAD, PACK_1X1_FPROP = range(6)
 MAX_CLASSES = 16
@@ -92,6 +93,17 @@ SIGNATURES = {
     "oct_nhwc_to_nchw": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_int,
                              c_void_p]),
+    "oct_affine_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int,
+                                   c_void_p]),
+    "oct_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "oct_maxpool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_maxpool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_bilinear_up_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_bilinear_up_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_depth_to_space": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_space_to_depth": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_gate_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oct_gate_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oct_confusion_counts": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
     "oct_sqdiff_sum": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
     "oct_column_absdiff_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_size_t, c_void_p, c_void_p]),

@@ -215,9 +215,9 @@ class UNetEngine:
         L.check(L.lib().oct_conv_forward(C.byref(d), C.byref(a), _stream()), "oct_conv_forward")
         self._prof_end(ev, "igemm")
 
-    def _stat_blocks(self, cout, n, h, w, src: Src):
+    def _stat_blocks(self, cout, n, h, w, src: Src, taps=9):
         """rows of the partial-statistics buffer the conv with this exact descriptor will write"""
-        d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, 9,
+        d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                        L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, 0, 0, 0, 1)
         return L.lib().oct_conv_stat_blocks(C.byref(d))

@@ -1,0 +1,376 @@
+"""Autograd ops over NHWC device tensors, each backed by the C ABI (include/oct_hip.h).
+
+The YNet/BioNet U-Nets run through `engine.UNetEngine`'s fused schedule (raw conv outputs, BN+ReLU
+applied on the consumer's load).  The reference's other block families -- MGUNet's UnetConv /
+UnetUp / UnetUp4 (MGUNet_2021.py:42-108) and SD_Layer_Net's conv_block / up_conv /
+Attention_block (common.py:6-91) -- mix residual sums, bilinear up-sampling, sigmoid gates and
+convolutions without BatchNorm, so they are composed from the ops below with materialised
+activations; torch.autograd only orders the calls and sums fan-out gradients.  Every tensor
+between ops is (N, H, W, C) in the compute dtype (bf16, or fp32 in parity mode).
+There is no CPU fallback: `_lib.lib()` raises when the HIP library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .engine import BN_EPS, BN_MOMENTUM, Src, UNetEngine, _stream
+
+_engines: dict = {}
+
+
+def kernels(dtype: str) -> UNetEngine:
+    """Launch helpers (weight packing cache, conv / wgrad descriptors) for one compute dtype."""
+    e = _engines.get(dtype)
+    if e is None:
+        e = _engines[dtype] = UNetEngine(1, 1, 4, dtype)
+    return e
+
+
+_PACK_SHAPE = {
+    L.PACK_CONV_FPROP: lambda co, ci: (co, 9, ci), L.PACK_CONV_DGRAD: lambda co, ci: (ci, 9, co),
+    L.PACK_DECONV_FPROP: lambda co, ci: (4 * co, 1, ci), L.PACK_DECONV_DGRAD: lambda co, ci: (ci, 1, 4 * co),
+    L.PACK_1X1_DGRAD: lambda co, ci: (ci, 1, co), L.PACK_1X1_FPROP: lambda co, ci: (co, 1, ci)}
+
+
+def packed(e: UNetEngine, w: torch.Tensor, mode: int, cout: int, cin: int, cache: bool = True) -> torch.Tensor:
+    """MFMA-fragment-ordered copy of a weight in the compute dtype.  The copy lives on the
+    parameter object itself (so it dies with it and can never be mistaken for another tensor that
+    later reuses the address) and is refreshed when torch's version counter or the raw-pointer
+    optimizer's generation moves."""
+    ver = (w._version, L.param_generation[0], w.data_ptr())
+    slot = (mode, e.dtype)
+    store = w.__dict__.setdefault("_oct_packed", {}) if cache else {}
+    hit = store.get(slot)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    rows, taps, kch = _PACK_SHAPE[mode](cout, cin)
+    out = torch.empty(L.lib().oct_packed_weight_elems(rows, taps, kch), dtype=e.tdt, device=w.device)
+    L.check(L.lib().oct_pack_weights(mode, e.dt, w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "oct_pack_weights")
+    store[slot] = (ver, out)
+    return out
+
+
+def _need_cuda(t: torch.Tensor):
+    if t.device.type != "cuda":
+        raise L.OctError("the HIP path needs a device tensor (there is no CPU fallback)")
+
+
+class ToNHWC(torch.autograd.Function):
+    """(N,C,H,W) float -> (N,H,W,C) compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _need_cuda(x)
+        e = kernels(dtype)
+        n, c, h, w = x.shape
+        xf = x.detach().to(torch.float32).contiguous()
+        out = e._act(n, h, w, c, x.device)
+        L.check(L.lib().oct_nchw_to_nhwc(e.dt, xf.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "oct_nchw_to_nhwc")
+        ctx.dtype = dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ToNCHW.apply(dout, ctx.dtype), None
+
+
+class ToNCHW(torch.autograd.Function):
+    """(N,H,W,C) compute dtype -> (N,C,H,W) fp32."""
+
+    @staticmethod
+    def forward(ctx, a, dtype):
+        e = kernels(dtype)
+        n, h, w, c = a.shape
+        a = a.contiguous()
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=a.device)
+        L.check(L.lib().oct_nhwc_to_nchw(e.dt, a.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "oct_nhwc_to_nchw")
+        ctx.dtype = dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ToNHWC.apply(dout, ctx.dtype), None
+
+
+class ConvAffineAct(torch.autograd.Function):
+    """out = act(affine(conv(cat(x0, x1), w)) (+ res)) with affine = train/eval BatchNorm (bn given) or
+    `+ bias` (bn None).  3x3 pad 1 or 1x1, chosen by the weight's shape.
+
+    bn: the nn.BatchNorm2d container (running buffers are updated in train mode, momentum 0.1).
+    A conv bias in front of a train-mode BN only moves the running mean; its gradient is zero."""
+
+    @staticmethod
+    def forward(ctx, dtype, bn, act, x0, x1, w, cbias, gamma, beta, res):
+        e = kernels(dtype)
+        lib = L.lib()
+        x0 = x0.contiguous()
+        n, h, wd, c0 = x0.shape
+        c1 = 0
+        if x1 is not None:
+            x1 = x1.contiguous()
+            c1 = x1.shape[3]
+        cout, cin, kh, _ = w.shape
+        if cin != c0 + c1 or kh not in (1, 3):
+            raise RuntimeError(f"conv weight {tuple(w.shape)} does not fit an input with {c0 + c1} channels")
+        taps = 9 if kh == 3 else 1
+        dev = x0.device
+        src = Src(x0, c0, None, x1, c1, None)
+        wp = packed(e, w, L.PACK_CONV_FPROP if taps == 9 else L.PACK_1X1_FPROP, cout, cin)
+        y = e._act(n, h, wd, cout, dev)
+        scale = torch.empty(cout, dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        mean = invstd = None
+        train_bn = bn is not None and bn.training
+        if train_bn:
+            nblk = e._stat_blocks(cout, n, h, wd, src, taps)
+            partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
+            e._conv(src, wp, cout, taps, n, h, wd, y, stats=partials)
+            mean, invstd = torch.empty_like(scale), torch.empty_like(scale)
+            L.check(lib.oct_bn_finalize(partials.data_ptr(), nblk, cout, float(n * h * wd), gamma.data_ptr(),
+                                        beta.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(),
+                                        bn.running_var.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                        scale.data_ptr(), shift.data_ptr(), L.ptr(cbias), _stream()), "oct_bn_finalize")
+            bn.num_batches_tracked.add_(1)
+        else:
+            e._conv(src, wp, cout, taps, n, h, wd, y)
+            if bn is not None:
+                L.check(lib.oct_bn_eval_coeffs(cout, gamma.data_ptr(), beta.data_ptr(),
+                                               bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_EPS,
+                                               scale.data_ptr(), shift.data_ptr(), L.ptr(cbias), _stream()),
+                        "oct_bn_eval_coeffs")
+            else:
+                scale.fill_(1.0)
+                if cbias is not None:
+                    shift.copy_(cbias.detach())
+                else:
+                    shift.zero_()
+        out = e._act(n, h, wd, cout, dev)
+        if res is not None:
+            res = res.contiguous()
+        L.check(lib.oct_affine_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), act,
+                                       out.data_ptr(), n * h * wd, cout, _stream()), "oct_affine_act_fwd")
+        ctx.cfg = (dtype, bn, act, taps, train_bn, res is not None, cbias is not None)
+        ctx.save_for_backward(x0, x1, w, y, out, mean, invstd, scale, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dtype, bn, act, taps, train_bn, has_res, has_bias = ctx.cfg
+        x0, x1, w, y, out, mean, invstd, scale, gamma = ctx.saved_tensors
+        e = kernels(dtype)
+        lib = L.lib()
+        n, h, wd, c0 = x0.shape
+        c1 = x1.shape[3] if x1 is not None else 0
+        cout, cin = w.shape[0], w.shape[1]
+        npix = n * h * wd
+        dev = x0.device
+        dout = dout.contiguous()
+        if bn is not None and not train_bn:
+            raise NotImplementedError("backward through an eval-mode BatchNorm is not on the HIP path")
+        if act != L.ACT_NONE:
+            dz = torch.empty_like(dout)
+            L.check(lib.oct_act_bwd(e.dt, dout.data_ptr(), out.data_ptr(), act, dz.data_ptr(), dz.numel(), _stream()),
+                    "oct_act_bwd")
+        else:
+            dz = dout
+        dres = dz if has_res else None
+        dgamma = dbeta = dcb = None
+        if bn is not None:
+            # sums of dz and dz*xhat: the reduction kernel of the fused path with its ReLU mask held open
+            nblk = lib.oct_dact_bn_reduce_blocks(n, h, wd, cout, 0)
+            partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
+            ones, zeros = torch.ones(cout, dtype=torch.float32, device=dev), torch.zeros(cout, dtype=torch.float32, device=dev)
+            L.check(lib.oct_dact_bn_reduce(e.dt, dz.data_ptr(), None, y.data_ptr(), zeros.data_ptr(), ones.data_ptr(),
+                                           mean.data_ptr(), invstd.data_ptr(), None, partials.data_ptr(), n, h, wd, cout,
+                                           _stream()), "oct_dact_bn_reduce")
+            dgamma, dbeta = torch.empty_like(scale), torch.empty_like(scale)
+            coef = torch.empty((3, cout), dtype=torch.float32, device=dev)
+            L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, cout, float(npix), gamma.data_ptr(),
+                                            mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                            coef.data_ptr(), 0, _stream()), "oct_bn_bwd_finalize")
+            dy = dz.clone() if (has_res or dz is dout) else dz
+            L.check(lib.oct_bn_bwd_apply(e.dt, dy.data_ptr(), y.data_ptr(), coef.data_ptr(), None, None, npix, cout,
+                                         _stream()), "oct_bn_bwd_apply")
+            if has_bias:
+                dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
+        else:
+            dy = dz
+            if has_bias:
+                dcb = torch.empty(cout, dtype=torch.float32, device=dev)
+                L.check(lib.oct_channel_sum(e.dt, dy.data_ptr(), dcb.data_ptr(), npix, cout, 0, _stream()),
+                        "oct_channel_sum")
+        src = Src(x0, c0, None, x1, c1, None)
+        dwp = e._wgrad(src, dy, cout, taps, n, h, wd)
+        dw = torch.empty_like(w)
+        e._unpack(L.PACK_CONV_FPROP if taps == 9 else L.PACK_1X1_FPROP, dwp, dw, cout, cin, False)
+        d0 = d1 = None
+        if ctx.needs_input_grad[3] or (x1 is not None and ctx.needs_input_grad[4]):  # x0 / x1
+            wp = packed(e, w, L.PACK_CONV_DGRAD if taps == 9 else L.PACK_1X1_DGRAD, cout, cin)
+            d0 = e._act(n, h, wd, c0, dev)
+            d1 = e._act(n, h, wd, c1, dev) if c1 else None
+            e._conv(Src(dy, cout), wp, cin, taps, n, h, wd, d0, y1=d1, split=c0 if c1 else 0)
+        return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres
+
+
+class MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dtype, k, a):
+        e = kernels(dtype)
+        a = a.contiguous()
+        n, h, w, c = a.shape
+        if h % k or w % k:
+            raise RuntimeError(f"max-pool window {k} does not divide {h}x{w}")
+        out = e._act(n, h // k, w // k, c, a.device)
+        L.check(L.lib().oct_maxpool_fwd(e.dt, a.data_ptr(), out.data_ptr(), n, h, w, c, k, _stream()), "oct_maxpool_fwd")
+        ctx.cfg = (dtype, k)
+        ctx.save_for_backward(a)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dtype, k = ctx.cfg
+        (a,) = ctx.saved_tensors
+        e = kernels(dtype)
+        n, h, w, c = a.shape
+        dout = dout.contiguous()
+        da = torch.empty_like(a)
+        L.check(L.lib().oct_maxpool_bwd(e.dt, a.data_ptr(), dout.data_ptr(), da.data_ptr(), n, h, w, c, k, _stream()),
+                "oct_maxpool_bwd")
+        return None, None, da
+
+
+class BilinearUp(torch.autograd.Function):
+    """x`factor` bilinear up-sampling with align_corners=True."""
+
+    @staticmethod
+    def forward(ctx, dtype, factor, x):
+        e = kernels(dtype)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        out = e._act(n, h * factor, w * factor, c, x.device)
+        L.check(L.lib().oct_bilinear_up_fwd(e.dt, x.data_ptr(), out.data_ptr(), n, h, w, c, factor, _stream()),
+                "oct_bilinear_up_fwd")
+        ctx.cfg = (dtype, factor, (n, h, w, c))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dtype, factor, (n, h, w, c) = ctx.cfg
+        e = kernels(dtype)
+        dout = dout.contiguous()
+        dx = e._act(n, h, w, c, dout.device)
+        L.check(L.lib().oct_bilinear_up_bwd(e.dt, dout.data_ptr(), dx.data_ptr(), n, h, w, c, factor, _stream()),
+                "oct_bilinear_up_bwd")
+        return None, None, dx
+
+
+class Deconv(torch.autograd.Function):
+    """nn.ConvTranspose2d(cin, cout, kernel_size=k, stride=k) with bias, k in {2, 4}.  k=2 stores
+    straight from the GEMM epilogue (depth-to-space fused); k=4 runs the (16*cout x cin) GEMM as a
+    1x1 convolution followed by oct_depth_to_space."""
+
+    @staticmethod
+    def forward(ctx, dtype, x, w, bias):
+        e = kernels(dtype)
+        x = x.contiguous()
+        n, h, wd, cin = x.shape
+        if w.shape[0] != cin or w.shape[2] != w.shape[3] or w.shape[2] not in (2, 4):
+            raise RuntimeError(f"transposed-conv weight {tuple(w.shape)} does not fit {cin} input channels / k in (2, 4)")
+        cout, k = w.shape[1], w.shape[2]
+        out = e._act(n, h * k, wd * k, cout, x.device)
+        if k == 2:
+            wp = packed(e, w, L.PACK_DECONV_FPROP, cout, cin)
+            e._conv(Src(x, cin), wp, 4 * cout, 1, n, h, wd, out, out_mode=L.OUT_D2S, bias=bias)
+            w1 = None
+        else:
+            w1 = w.detach().permute(2, 3, 1, 0).reshape(k * k * cout, cin, 1, 1).contiguous()
+            wp = packed(e, w1, L.PACK_1X1_FPROP, k * k * cout, cin, cache=False)   # w1 is a temporary
+            y = e._act(n, h, wd, k * k * cout, x.device)
+            e._conv(Src(x, cin), wp, k * k * cout, 1, n, h, wd, y)
+            L.check(L.lib().oct_depth_to_space(e.dt, y.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, wd, cout, k,
+                                               _stream()), "oct_depth_to_space")
+        ctx.cfg = (dtype, k)
+        ctx.save_for_backward(x, w, w1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dtype, k = ctx.cfg
+        x, w, w1 = ctx.saved_tensors
+        e = kernels(dtype)
+        lib = L.lib()
+        n, h, wd, cin = x.shape
+        cout = w.shape[1]
+        dev = x.device
+        dout = dout.contiguous()
+        dw = torch.empty_like(w)
+        db = torch.zeros(cout, dtype=torch.float32, device=dev)
+        dx = None
+        if k == 2:
+            dwp = e._wgrad(Src(x, cin), dout, 4 * cout, 1, n, h, wd, dy_mode=L.IN_S2D, dbias=db)
+            e._unpack(L.PACK_DECONV_FPROP, dwp, dw, cout, cin, False)
+            if ctx.needs_input_grad[1]:
+                wp = packed(e, w, L.PACK_DECONV_DGRAD, cout, cin)
+                dx = e._act(n, h, wd, cin, dev)
+                e._conv(Src(dout, cout), wp, cin, 1, n, h, wd, dx, in_mode=L.IN_S2D)
+        else:
+            rows = k * k * cout
+            L.check(lib.oct_channel_sum(e.dt, dout.data_ptr(), db.data_ptr(), n * h * k * wd * k, cout, 0, _stream()),
+                    "oct_channel_sum")
+            dyd = e._act(n, h, wd, rows, dev)
+            L.check(lib.oct_space_to_depth(e.dt, dout.data_ptr(), dyd.data_ptr(), n, h, wd, cout, k, _stream()),
+                    "oct_space_to_depth")
+            dwp = e._wgrad(Src(x, cin), dyd, rows, 1, n, h, wd)
+            g1 = torch.empty_like(w1)
+            e._unpack(L.PACK_1X1_FPROP, dwp, g1, rows, cin, False)
+            dw = g1.reshape(k, k, cout, cin).permute(3, 2, 0, 1).contiguous()
+            if ctx.needs_input_grad[1]:
+                wp = packed(e, w1, L.PACK_1X1_DGRAD, rows, cin, cache=False)
+                dx = e._act(n, h, wd, cin, dev)
+                e._conv(Src(dyd, rows), wp, cin, 1, n, h, wd, dx)
+        return None, dx, dw, db
+
+
+class Gate(torch.autograd.Function):
+    """out[n,h,w,c] = x[n,h,w,c] * p[n,h,w,0]  (Attention_block's `x * psi`, common.py:91)."""
+
+    @staticmethod
+    def forward(ctx, dtype, x, p):
+        e = kernels(dtype)
+        x, p = x.contiguous(), p.contiguous()
+        n, h, w, c = x.shape
+        out = torch.empty_like(x)
+        L.check(L.lib().oct_gate_fwd(e.dt, x.data_ptr(), p.data_ptr(), out.data_ptr(), n * h * w, c, _stream()),
+                "oct_gate_fwd")
+        ctx.dtype = dtype
+        ctx.save_for_backward(x, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, p = ctx.saved_tensors
+        e = kernels(ctx.dtype)
+        n, h, w, c = x.shape
+        dout = dout.contiguous()
+        dx, dp = torch.empty_like(x), torch.empty_like(p)
+        L.check(L.lib().oct_gate_bwd(e.dt, dout.data_ptr(), x.data_ptr(), p.data_ptr(), dx.data_ptr(), dp.data_ptr(),
+                                     n * h * w, c, _stream()), "oct_gate_bwd")
+        return None, dx, dp
+
+
+# ---- functional spellings -----------------------------------------------------------------------
+def conv_bn_act(dtype, x0, conv, bn=None, act=L.ACT_NONE, x1=None, res=None):
+    """conv: nn.Conv2d container (3x3 pad 1 or 1x1); bn: nn.BatchNorm2d container or None."""
+    return ConvAffineAct.apply(dtype, bn, act, x0, x1, conv.weight, conv.bias,
+                               bn.weight if bn is not None else None, bn.bias if bn is not None else None, res)
+
+
+def to_nhwc(x, dtype):
+    return ToNHWC.apply(x, dtype)
+
+
+def to_nchw(a, dtype):
+    return ToNCHW.apply(a, dtype)
