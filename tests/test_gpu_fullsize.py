@@ -1,0 +1,138 @@
+"""BASELINE.json's configurations at their full sizes on the GPU, through size-independent
+properties (no CPU oracle finishes cfg2 in test time) plus CPU-restatement comparisons where one
+sample is cheap enough.
+
+  cfg1  BioNet_2020.UNet(1, 2), B=4, 256x256         fp32 mode vs the torch restatement on the host
+  cfg2  YNet_2022 UNet(1, 8), B=32, 512x1024, bf16   properties
+  cfg4  AttU_Net(1, 3), B=16, 496x768, bf16          properties; one sample in fp32 vs the restatement
+
+Tolerances: north_star asks for identical arg-max maps and Dice/IoU within 1e-5.  Arg-max equality
+is asserted where the comparison partner's own top-2 margin exceeds 1e-4 (a near-tie may flip from
+fp32 summation order alone); Dice/IoU of the two arg-max maps against the labels within 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def safe_mask(logits_ref, margin=1e-4):
+    top2 = torch.sort(logits_ref, dim=1).values[:, -2:]
+    return (top2[:, 1] - top2[:, 0]) > margin
+
+
+def dice_iou(pred, target, c):
+    from retinal_oct_image_segmentation_via_deep_learning_amd.Metrics.Region_based_metrics import dice_coefficient, iou_score
+    return float(dice_coefficient(target == c, pred == c)), float(iou_score(target == c, pred == c))
+
+
+def test_cfg1_bionet_unet_f32_matches_host_restatement():
+    from oracle.torch_unet import TorchBioUNet
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment.BioNet_2020 import UNet
+    torch.manual_seed(3)
+    ref = TorchBioUNet(1, 2).train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(4, 1, 256, 256, generator=g)
+    t = torch.randint(0, 2, (4, 256, 256), generator=g)
+    model = UNet(1, 2, compute_dtype="f32")
+    model.load_state_dict(ref.state_dict())
+    model.cuda().train()
+    out = model(x.cuda())
+    lr = ref(x)
+    assert (out.detach().cpu() - lr.detach()).abs().max() < 1e-3 * max(1.0, float(lr.detach().abs().max()))
+    safe = safe_mask(lr.detach())
+    assert safe.float().mean() > 0.999
+    pg, pr = out.argmax(1).cpu(), lr.argmax(1)
+    assert torch.equal(pg[safe], pr[safe])
+    for c in (0, 1):
+        (dg, ig), (dr, ir) = dice_iou(pg.cuda(), t.cuda(), c), dice_iou(pr.numpy(), t.numpy(), c)
+        assert abs(dg - dr) < 1e-5 and abs(ig - ir) < 1e-5
+    F.cross_entropy(out, t.cuda()).backward()
+    F.cross_entropy(lr, t).backward()
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if k.endswith((".0.bias", ".3.bias")):
+            continue
+        a, b = p.grad.flatten().double().cpu(), q.grad.flatten().double()
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 2e-2, k      # fp32 vs fp32, different summation orders
+
+
+def test_cfg2_unet_bf16_full_batch_properties():
+    from retinal_oct_image_segmentation_via_deep_learning_amd import UNet
+    from retinal_oct_image_segmentation_via_deep_learning_amd.optim import FusedSGD
+    torch.manual_seed(0)
+    model = UNet(1, 8).cuda().train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(32, 1, 512, 1024, generator=g).cuda()
+    t = torch.randint(0, 8, (32, 512, 1024), generator=g).cuda()
+    opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9)
+    losses = []
+    for _ in range(4):
+        losses.append(float(model.forward_backward(x, t)[0]))
+        opt.step()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    model.eval()
+    with torch.no_grad():
+        probs = model(x)
+        assert probs.shape == (32, 8, 512, 1024)
+        assert float((probs.sum(1) - 1).abs().max()) < 1e-5 and float(probs.min()) >= 0
+        pred = model.predict(x)
+        assert torch.equal(pred, probs.argmax(1))                        # same first-maximum rule
+        loss = model.loss(x, t)
+        ce = F.nll_loss(torch.log(probs), t)
+        assert abs(float(loss[1]) - float(ce)) < 1e-5 * max(1.0, float(ce))
+        # a B-scan's eval-mode output does not depend on its batch neighbours
+        alone = model(x[5:6])
+        assert torch.equal(alone[0], probs[5])
+        # device metrics == host oracle metrics on the same full-size maps (Dice/IoU within 1e-5)
+        from oracle import ref_cpu
+        pn, tn = pred.cpu().numpy(), t.cpu().numpy()
+        for c in (0, 3):
+            d, i = dice_iou(pred, t, c)
+            assert abs(d - ref_cpu.dice_coefficient(tn == c, pn == c)) < 1e-5
+            assert abs(i - ref_cpu.iou_score(tn == c, pn == c)) < 1e-5
+    # bf16 production mode tracks fp32 parity mode at full resolution (4 B-scans)
+    model.set_compute_dtype("f32")
+    with torch.no_grad():
+        p32 = model(x[:4])
+    agree = (p32.argmax(1) == probs[:4].argmax(1)).float().mean()
+    assert float(agree) > 0.97 and float((p32 - probs[:4]).abs().mean()) < 5e-3
+
+
+def test_cfg4_attunet_full_size():
+    from oracle.torch_blocks import AttU_Net as TorchAttUNet
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment.SD_Layer_Net.unet import AttU_Net
+    torch.manual_seed(4)
+    model = AttU_Net(1, 3).cuda().train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(16, 1, 496, 768, generator=g).cuda()
+    t = torch.randint(0, 3, (16, 496, 768), generator=g).cuda()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        loss = F.cross_entropy(out, t)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert out.shape == (16, 3, 496, 768)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    del out, loss
+    # one B-scan in fp32 parity mode against the torch restatement on the host (same weights)
+    ref = TorchAttUNet(1, 3)
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    ref.eval()
+    model.eval().set_compute_dtype("f32")
+    with torch.no_grad():
+        lg = model(x[:1]).cpu()
+        lr = ref(x[:1].cpu())
+    assert (lg - lr).abs().max() < 2e-3 * max(1.0, float(lr.detach().abs().max()))
+    safe = safe_mask(lr)
+    assert torch.equal(lg.argmax(1)[safe], lr.argmax(1)[safe])
+    for c in range(3):
+        (dg, ig), (dr, ir) = dice_iou(lg.argmax(1).numpy(), t[:1].cpu().numpy(), c), dice_iou(lr.argmax(1).numpy(), t[:1].cpu().numpy(), c)
+        assert abs(dg - dr) < 1e-5 and abs(ig - ir) < 1e-5
