@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay forward+loss+backward as one HIP graph (no gain at batch 32: the queue never runs dry)")
     args = ap.parse_args()
 
     import torch
@@ -71,7 +73,8 @@ def main():
 
     torch.manual_seed(0)
     model = UNet(1, args.classes, init_features=args.features, compute_dtype="bf16").to(dev).train()
-    trainer = ddp.DataParallelTrainer(model, lr=0.01, momentum=0.9)
+    trainer = ddp.DataParallelTrainer(model, lr=0.01, momentum=0.9, use_graph=args.graph,
+                                      graph_warmup=max(1, min(2, args.warmup - 1)))
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(args.batch, 1, args.height, args.width, generator=g).to(dev)
     t = torch.randint(0, args.classes, (args.batch, args.height, args.width), generator=g).to(dev)
@@ -98,6 +101,8 @@ def main():
 
     # ---- roofline of the MFMA conv stack: one extra step with events around every conv launch ----
     flops_bscan = train_flops(args.features, args.classes, args.height, args.width)
+    graph_used, trainer.graph = trainer.graph is not None, None     # the measuring step below runs eagerly
+    trainer.use_graph = False
     model._engine.prof = []
     trainer.step(x, t)
     torch.cuda.synchronize()
@@ -143,7 +148,8 @@ def main():
                                    f"train step, {args.height}x{args.width}, batch {args.batch}/GPU "
                                    f"(BASELINE configs[1]{'/[2] data-parallel' if world > 1 else ''})",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "step": "fwd + CE loss + bwd + grad all-reduce + SGD(momentum)"},
+                       "step": "fwd + CE loss + bwd + grad all-reduce + SGD(momentum)",
+                       "hip_graph": graph_used, "hip_graph_error": trainer.graph_error},
             "loss": float(loss[0].item()),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

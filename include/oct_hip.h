@@ -220,13 +220,15 @@ int oct_head_dlogits(const OctHeadDesc* d, const void* y, const float* scale, co
 /* Fused head backward (feat == 32 only, else OCT_E_INVALID -> use the pieces above): in one pass over
  * y it writes dlogits (optional, NHWC dtype; needed by oct_conv_wgrad for dW), dA = W^T dlogits
  * (NHWC dtype, [n,h,w,feat], UNMASKED: pair it with oct_bn_bwd_apply(scale, shift)), the BN-backward
- * partial sums of the masked gradient [oct_head_blocks][2][feat] and the bias gradient (atomics into
- * dbias[classes]; caller zeroes).                                                              */
+ * partial sums of the masked gradient [oct_head_blocks][2][feat], the bias gradient (atomics into
+ * dbias[classes]; caller zeroes) and -- when dweight is not NULL (classes <= 8) -- the weight gradient
+ * dW[c][f] = sum dlogits[c]*relu(bn(y))[f] (atomics into dweight[classes][feat], torch layout
+ * (Cout,Cin,1,1); caller zeroes), in which case dlogits may be NULL and is then never written.     */
 int oct_head_backward_fused(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
                             const float* mean, const float* invstd, const float* w, const float* b,
                             const int64_t* target, const float* dice_coef, float w_ce,
                             const float* dprobs, void* dlogits, void* da, float* partials,
-                            float* dbias, void* stream);
+                            float* dbias, float* dweight, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / dtype helpers and the optimizer

@@ -88,7 +88,7 @@ SIGNATURES = {
                                  c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "oct_head_backward_fused": (c_int, [C.POINTER(HeadDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p]),
     "oct_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_nhwc_to_nchw": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_int,

@@ -1,9 +1,9 @@
 // First layer of the U-Net (Conv2d(1 -> F, 3x3), YNet_2022.py:578 with in_channels = 1): K = 9 is
 // far too shallow for MFMA -- this is a bandwidth stencil.  Direct VALU kernels:
-//   fprop : one thread per pixel, 9 taps x F outputs from scalar-cached weights, 64-B NHWC store,
-//           BatchNorm partial sums kept in registers over a grid-stride loop;
-//   wgrad : one thread per (pixel, 8-channel group), 72 register accumulators, one LDS + atomic
-//           reduction per workgroup.
+//   fprop : one thread per (pixel, 8-channel group), the 72 filter taps of the group in registers,
+//           16-B NHWC stores contiguous across lanes, BatchNorm partial sums in registers;
+//   wgrad : the same mapping, 72 register accumulators, one LDS + atomic reduction per workgroup.
+// Both keep the loads of the next pixel in flight while the current one is processed.
 // bf16 only; other dtypes / channel counts use the generic implicit-GEMM kernels.
 #include "common.h"
 #include <stdlib.h>
@@ -18,57 +18,74 @@ __device__ __forceinline__ unsigned f1_pack(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
+// the 3x3 neighbourhood of pixel q of a single-channel image, zero outside; loads are unconditional
+// (clamped to q itself) so that they can be issued an iteration ahead without divergent control flow
+__device__ __forceinline__ void f1_taps(const bf16_t* __restrict__ x, unsigned q, int h, int w, float (&v)[9]) {
+  const int xx = q % (unsigned)w;
+  const int yy = (q / (unsigned)w) % (unsigned)h;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int dy = t / 3 - 1, dx = t % 3 - 1;
+    const bool ok = (yy + dy >= 0) && (yy + dy < h) && (xx + dx >= 0) && (xx + dx < w);
+    const float val = (float)x[ok ? (int)q + dy * w + dx : (int)q];
+    v[t] = ok ? val : 0.f;
+  }
+}
+
+// fprop: a thread owns (pixel, 8-channel group): its 72 filter taps stay in registers for the whole
+// kernel, consecutive lanes store consecutive 16-B chunks (1 KB per wave instruction), the taps of
+// the next pixel are loaded while the current one is computed.
 template <int F>
 __global__ void __launch_bounds__(256) first_fprop_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
                                                           bf16_t* __restrict__ y, float* __restrict__ stats, int n,
                                                           int h, int w) {
   // wp: the MFMA fragment-order packing of the (F,1,3,3) filter (OCT_PACK_CONV_FPROP, nk16 = 1):
   // A[row = co][k = 0] sits at ((co/32 * 9 + tap) * 512 + (co%32) * 8)
-  __shared__ float sw[9 * F];
+  constexpr int G = F / 8, PPB = 256 / G;
   __shared__ float red[4][2][F];
-  for (int i = threadIdx.x; i < 9 * F; i += 256) {
-    const int co = i % F, tap = i / F;
-    sw[i] = (float)wp[((co >> 5) * 9 + tap) * 512 + (co & 31) * 8];
-  }
-  __syncthreads();
-  float s1[F], s2[F];
+  const int g = threadIdx.x % G, slot = threadIdx.x / G;
+  float wv[9][8];
 #pragma unroll
-  for (int c = 0; c < F; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-  const size_t npix = (size_t)n * h * w;
-  for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * 256) {
-    const int xx = pix % w;
-    const int yy = (pix / w) % h;
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int co = g * 8 + j;
+      wv[t][j] = (float)wp[((co >> 5) * 9 + t) * 512 + (co & 31) * 8];
+    }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const unsigned npix = (unsigned)n * h * w, stride = gridDim.x * PPB;
+  unsigned pix = blockIdx.x * PPB + slot;
+  float vn[9];
+  f1_taps(x, pix < npix ? pix : 0u, h, w, vn);
+  for (; pix < npix; pix += stride) {
     float v[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3 - 1, dx = t % 3 - 1;
-      const bool ok = (yy + dy >= 0) && (yy + dy < h) && (xx + dx >= 0) && (xx + dx < w);
-      v[t] = ok ? (float)x[pix + (ptrdiff_t)dy * w + dx] : 0.f;
-    }
-    float acc[F];
+    for (int t = 0; t < 9; ++t) v[t] = vn[t];
+    f1_taps(x, pix + stride < npix ? pix + stride : pix, h, w, vn);
+    float acc[8];
 #pragma unroll
-    for (int c = 0; c < F; ++c) acc[c] = 0.f;
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int c = 0; c < F; ++c) acc[c] = fmaf(sw[t * F + c], v[t], acc[c]);
-#pragma unroll
-    for (int c = 0; c < F; c += 8) {
-      const u32x4 o = {f1_pack(acc[c], acc[c + 1]), f1_pack(acc[c + 2], acc[c + 3]), f1_pack(acc[c + 4], acc[c + 5]),
-                       f1_pack(acc[c + 6], acc[c + 7])};
-      *reinterpret_cast<u32x4*>(y + pix * F + c) = o;
-    }
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv[t][j], v[t], acc[j]);
+    const u32x4 o = {f1_pack(acc[0], acc[1]), f1_pack(acc[2], acc[3]), f1_pack(acc[4], acc[5]), f1_pack(acc[6], acc[7])};
+    *reinterpret_cast<u32x4*>(y + (size_t)pix * F + g * 8) = o;
     if (stats) {
 #pragma unroll
-      for (int c = 0; c < F; ++c) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
+      for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
     }
   }
   if (stats) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < F; ++c) {
-      const float a = wave_sum(s1[c]), b = wave_sum(s2[c]);
-      if (lane == 0) { red[wave][0][c] = a; red[wave][1][c] = b; }
+    for (int j = 0; j < 8; ++j) {
+      float a = s1[j], b = s2[j];
+#pragma unroll
+      for (int o = 32; o >= G; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if (lane < G) { red[wave][0][g * 8 + j] = a; red[wave][1][g * 8 + j] = b; }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * F; i += 256) {
@@ -78,12 +95,15 @@ __global__ void __launch_bounds__(256) first_fprop_kernel(const bf16_t* __restri
   }
 }
 
+// wgrad: the same (pixel, 8-channel group) mapping, 72 register accumulators, one LDS + atomic
+// reduction per workgroup; dY (and y for the fused BN-backward apply) of the next pixel are in flight
+// while the current one is accumulated.
 template <int F>
 __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                           float* __restrict__ dwp, int n, int h, int w,
                                                           const bf16_t* __restrict__ yraw, const float* __restrict__ coef,
                                                           const float* __restrict__ scale, const float* __restrict__ shift) {
-  constexpr int G = F / 8;
+  constexpr int G = F / 8, PPB = 256 / G;
   __shared__ float sacc[9 * F];
   for (int i = threadIdx.x; i < 9 * F; i += 256) sacc[i] = 0.f;
   __syncthreads();
@@ -92,8 +112,7 @@ __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restri
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-  const size_t npix = (size_t)n * h * w, total = npix * G;
-  const int g = threadIdx.x % G;  // 256 % G == 0: the channel group of a thread is loop invariant
+  const int g = threadIdx.x % G, slot = threadIdx.x / G;
   // fused BN-backward apply: dy = k0*[z>0]*dA + k1*y + k2 (per-channel constants of this thread's group)
   float k0[8], k1[8], k2[8], sc[8], sh[8];
   if (coef) {
@@ -103,32 +122,44 @@ __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restri
       sc[j] = scale[g * 8 + j]; sh[j] = shift[g * 8 + j];
     }
   }
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t pix = i / G;
-    const int xx = pix % w;
-    const int yy = (pix / w) % h;
-    const u32x4 d = *reinterpret_cast<const u32x4*>(dy + pix * F + g * 8);
+  const unsigned npix = (unsigned)n * h * w, stride = gridDim.x * PPB;
+  unsigned pix = blockIdx.x * PPB + slot;
+  const bf16_t* ysrc = coef ? yraw : dy;     // one unconditional load either way
+  u32x4 dn, yn;
+  float vn[9];
+  {
+    const unsigned q = pix < npix ? pix : 0u;
+    dn = *reinterpret_cast<const u32x4*>(dy + (size_t)q * F + g * 8);
+    yn = *reinterpret_cast<const u32x4*>(ysrc + (size_t)q * F + g * 8);
+    f1_taps(x, q, h, w, vn);
+  }
+  for (; pix < npix; pix += stride) {
+    const u32x4 d = dn, yq = yn;
+    float xv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) xv[t] = vn[t];
+    {
+      const unsigned q = pix + stride < npix ? pix + stride : pix;
+      dn = *reinterpret_cast<const u32x4*>(dy + (size_t)q * F + g * 8);
+      yn = *reinterpret_cast<const u32x4*>(ysrc + (size_t)q * F + g * 8);
+      f1_taps(x, q, h, w, vn);
+    }
     float dv[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { dv[2 * j] = __uint_as_float(d[j] << 16); dv[2 * j + 1] = __uint_as_float(d[j] & 0xffff0000u); }
     if (coef) {
-      const u32x4 yy = *reinterpret_cast<const u32x4*>(yraw + pix * F + g * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float yv = (j & 1) ? __uint_as_float(yy[j >> 1] & 0xffff0000u) : __uint_as_float(yy[j >> 1] << 16);
+        const float yv = (j & 1) ? __uint_as_float(yq[j >> 1] & 0xffff0000u) : __uint_as_float(yq[j >> 1] << 16);
         const float gm = fmaf(yv, sc[j], sh[j]) > 0.f ? dv[j] : 0.f;
         // rounded to the activation dtype, exactly what the unfused apply pass would have stored
         dv[j] = (float)(bf16_t)fmaf(k0[j], gm, fmaf(k1[j], yv, k2[j]));
       }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int ddy = t / 3 - 1, ddx = t % 3 - 1;
-      const bool ok = (yy + ddy >= 0) && (yy + ddy < h) && (xx + ddx >= 0) && (xx + ddx < w);
-      const float xv = ok ? (float)x[pix + (ptrdiff_t)ddy * w + ddx] : 0.f;
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(dv[j], xv, acc[t][j]);
-    }
+      for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(dv[j], xv[t], acc[t][j]);
   }
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -153,9 +184,9 @@ static bool first_ok(int dtype, int c0, int c1, int cout, int taps) {
   return f1_enabled() && dtype == OCT_DT_BF16 && c0 == 1 && c1 == 0 && taps == 9 && (cout == 16 || cout == 32 || cout == 64);
 }
 static int first_grid(const OctConvDesc* d) {
-  const size_t npix = (size_t)d->n * d->h * d->w;
-  size_t b = (npix + 255) / 256;
-  if (b > 2048) b = 2048;
+  const size_t work = (size_t)d->n * d->h * d->w * (d->cout / 8);   // a thread per (pixel, 8-channel group)
+  size_t b = (work + 255) / 256;
+  if (b > 4096) b = 4096;
   return (int)b;
 }
 
@@ -181,8 +212,9 @@ int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) 
   if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
   if (a->dy_coef && (!a->dy_y || !a->dy_scale || !a->dy_shift)) { oct_set_error("oct_conv_wgrad: fused apply needs y, scale, shift"); return OCT_E_INVALID; }
   const size_t total = (size_t)d->n * d->h * d->w * (d->cout / 8);
+  if ((size_t)d->n * d->h * d->w >= (1u << 31)) return 0;   // 32-bit pixel arithmetic in the kernel
   size_t b = (total + 255) / 256;
-  if (b > 2048) b = 2048;
+  if (b > 4096) b = 4096;
   hipStream_t s = as_stream(stream);
 #define LAUNCH(F) hipLaunchKernelGGL(first_wgrad_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
                                      (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \

@@ -217,49 +217,98 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_dlogits_kernel(const HeadPa
 }
 
 // Fused head backward for feat == 32: d(loss)/d(logits), the 1x1 data gradient dA = W^T dlogits, the
-// bias gradient, and the BatchNorm-backward partial sums of the layer feeding the head -- one pass
-// over y instead of (dlogits kernel + 1x1 implicit GEMM + ReLU/BN reduction pass).
-template <typename T, int CMAX>
+// bias and weight gradients, and the BatchNorm-backward partial sums of the layer feeding the head --
+// one pass over y instead of (dlogits kernel + 1x1 implicit GEMM + 1x1 wgrad + ReLU/BN reduction).
+//
+// Four lanes share a pixel, each owning 8 of the 32 features: the 64-B feature row and the 64-B dA
+// row of a pixel are one 16-B access per lane (a wave instruction moves 1 KB contiguously), the
+// lane's 8 x classes slice of W lives in registers for the whole kernel (no LDS traffic in the
+// loop), logits are completed with two quad-permute adds, and the next pixel's row and label are
+// loaded before the current one is processed.
+__device__ __forceinline__ float quad_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
+template <typename T, int CMAX, bool DW>
 __global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const HeadParams p, const float* __restrict__ mean,
                                                                        const float* __restrict__ invstd, T* __restrict__ da_out,
-                                                                       float* __restrict__ partials, float* __restrict__ dbias) {
-  constexpr int F = 32;
-  __shared__ float sw[OCT_MAX_CLASSES * F];
-  __shared__ float sb[OCT_MAX_CLASSES], ssc[F], ssh[F], smu[F], sis[F];
-  __shared__ float sdc[2 * OCT_MAX_CLASSES];
+                                                                       float* __restrict__ partials, float* __restrict__ dbias,
+                                                                       float* __restrict__ dweight) {
+  constexpr int F = 32, G = 4, PPB = HEAD_THREADS / G;   // pixels per block per iteration
   __shared__ float red[HEAD_THREADS / 64][2 * F + OCT_MAX_CLASSES];
-  for (int i = threadIdx.x; i < F; i += blockDim.x) { smu[i] = mean[i]; sis[i] = invstd[i]; }
-  if (p.dice_coef) for (int i = threadIdx.x; i < 2 * OCT_MAX_CLASSES; i += blockDim.x) sdc[i] = p.dice_coef[i];
-  head_load_consts(p, sw, sb, ssc, ssh);
+  __shared__ float sdw[DW ? CMAX * F : 1];
+  const int g = threadIdx.x & 3, slot = threadIdx.x >> 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float w[CMAX][8], bias[CMAX], sc[8], sh[8], mu[8], is[8], dcA[CMAX], dcB[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    bias[c] = c < p.classes ? p.b[c] : 0.f;
+    dcA[c] = (p.dice_coef && c < p.classes) ? p.dice_coef[c] : 0.f;
+    dcB[c] = (p.dice_coef && c < p.classes) ? p.dice_coef[OCT_MAX_CLASSES + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[c][j] = c < p.classes ? p.w[c * F + g * 8 + j] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = p.scale[g * 8 + j]; sh[j] = p.shift[g * 8 + j]; mu[j] = mean[g * 8 + j]; is[j] = invstd[g * 8 + j];
+  }
+  if (DW) {
+    for (int i = threadIdx.x; i < CMAX * F; i += HEAD_THREADS) sdw[i] = 0.f;
+    __syncthreads();
+  }
   const size_t hw = (size_t)p.h * p.wd, npix = (size_t)p.n * hw;
   const float inv_n = 1.f / (float)npix;
-  float s1[F], s2[F], sdb[CMAX];
+  float s1[8], s2[8], sdb[CMAX], dwa[DW ? CMAX : 1][8];
 #pragma unroll
-  for (int k = 0; k < F; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) sdb[c] = 0.f;
+  for (int c = 0; c < CMAX; ++c) {
+    sdb[c] = 0.f;
+    if (DW) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dwa[c][j] = 0.f;
+    }
+  }
   T* dl_out = reinterpret_cast<T*>(p.dlogits);
-  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
-    const T* yp = reinterpret_cast<const T*>(p.y) + pix * F;
-    float yv[F], z[F], l[CMAX], pr[CMAX], dl[CMAX], dp[CMAX], m, lse;
+  const T* ybase = reinterpret_cast<const T*>(p.y);
+  const size_t stride = (size_t)gridDim.x * PPB;
+  size_t pix = (size_t)blockIdx.x * PPB + slot;
+  // software pipeline: the row and label of the next pixel are in flight while this one is processed
+  float yn[8];
+  int tn = 0;
+  {
+    const size_t q = pix < npix ? pix : 0;
+    load_vec<T, 8>(ybase + q * F + g * 8, yn);
+    if (p.target) tn = (int)p.target[q];
+  }
+  for (; pix < npix; pix += stride) {
+    float yv[8], z[8], a[8], l[CMAX], pr[CMAX], dl[CMAX], m, lse;
+    const int t = tn;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) l[c] = (c < p.classes) ? sb[c] : 0.f;
+    for (int j = 0; j < 8; ++j) yv[j] = yn[j];
+    {
+      const size_t q = pix + stride < npix ? pix + stride : pix;   // last iteration: harmless re-read
+      load_vec<T, 8>(ybase + q * F + g * 8, yn);
+      if (p.target) tn = (int)p.target[q];
+    }
 #pragma unroll
-    for (int f0 = 0; f0 < F; f0 += 8) {
-      load_vec<T, 8>(yp + f0, reinterpret_cast<float(&)[8]>(yv[f0]));
+    for (int j = 0; j < 8; ++j) { z[j] = fmaf(yv[j], sc[j], sh[j]); a[j] = fmaxf(z[j], 0.f); }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        z[f0 + j] = fmaf(yv[f0 + j], ssc[f0 + j], ssh[f0 + j]);
-        const float a = fmaxf(z[f0 + j], 0.f);
+    for (int c = 0; c < CMAX; ++c) {
+      float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
-          if (c < p.classes) l[c] = fmaf(sw[c * F + f0 + j], a, l[c]);
-      }
+      for (int j = 0; j < 8; ++j) s = fmaf(w[c][j], a[j], s);
+      s += quad_xor1(s);
+      s += quad_xor2(s);
+      l[c] = s + bias[c];
     }
     softmax_c<CMAX>(p.classes, l, pr, m, lse);
     if (p.dprobs) {
       const size_t img = pix / hw, off = pix - img * hw;
-      float dot = 0.f;
+      float dp[CMAX], dot = 0.f;
 #pragma unroll
       for (int c = 0; c < CMAX; ++c) {
         dp[c] = (c < p.classes) ? p.dprobs[(img * p.classes + c) * hw + off] : 0.f;
@@ -268,12 +317,10 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const Head
 #pragma unroll
       for (int c = 0; c < CMAX; ++c) dl[c] = pr[c] * (dp[c] - dot);
     } else {
-      const int t = (int)p.target[pix];
-      float dot = 0.f;
+      float dp[CMAX], dot = 0.f;
 #pragma unroll
       for (int c = 0; c < CMAX; ++c) {
-        dp[c] = 0.f;
-        if (p.dice_coef && c < p.classes) dp[c] = (c == t ? sdc[c] : 0.f) + sdc[OCT_MAX_CLASSES + c];
+        dp[c] = (c == t ? dcA[c] : 0.f) + dcB[c];
         dot = fmaf(pr[c], dp[c], dot);
       }
 #pragma unroll
@@ -283,37 +330,59 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const Head
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
       dl[c] = (c < p.classes) ? to_f32(from_f32<T>(dl[c])) : 0.f;
-      sdb[c] += dl[c];
-      if (dl_out && c < p.classes) dl_out[pix * p.classes + c] = from_f32<T>(dl[c]);
+      if (g == 0) sdb[c] += dl[c];
     }
+    if (dl_out && g == 0) {
 #pragma unroll
-    for (int f0 = 0; f0 < F; f0 += 8) {
-      float dav[8];
+      for (int c = 0; c < CMAX; ++c)
+        if (c < p.classes) dl_out[pix * p.classes + c] = from_f32<T>(dl[c]);
+    }
+    float dav[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) d = fmaf(w[c][j], dl[c], d);
+      dav[j] = d;
+      const float dr = to_f32(from_f32<T>(d));   // dA as stored
+      const float gm = z[j] > 0.f ? dr : 0.f;
+      s1[j] += gm;
+      s2[j] = fmaf(gm, (yv[j] - mu[j]) * is[j], s2[j]);
+    }
+    store_vec<T, 8>(da_out + pix * F + g * 8, dav);
+    if (DW) {
+      // dW[c][f] = sum_pix dlogits[c] * a[f], with a as the weight-gradient GEMM would read it (dtype-rounded)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float d = 0.f;
+        const float ar = to_f32(from_f32<T>(a[j]));
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
-          if (c < p.classes) d = fmaf(sw[c * F + f0 + j], dl[c], d);
-        const float dr = to_f32(from_f32<T>(d));   // dA as stored
-        dav[j] = d;
-        const float g = z[f0 + j] > 0.f ? dr : 0.f;
-        s1[f0 + j] += g;
-        s2[f0 + j] = fmaf(g, (yv[f0 + j] - smu[f0 + j]) * sis[f0 + j], s2[f0 + j]);
+        for (int c = 0; c < CMAX; ++c) dwa[c][j] = fmaf(dl[c], ar, dwa[c][j]);
       }
-      store_vec<T, 8>(da_out + pix * F + f0, dav);
     }
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // lanes with equal g hold the same feature group: fold the 16 pixel slots of a wave together
 #pragma unroll
-  for (int k = 0; k < F; ++k) {
-    const float a = wave_sum(s1[k]), b = wave_sum(s2[k]);
-    if (lane == 0) { red[wave][k] = a; red[wave][F + k] = b; }
+  for (int j = 0; j < 8; ++j) {
+    float a = s1[j], b = s2[j];
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (lane < G) { red[wave][g * 8 + j] = a; red[wave][F + g * 8 + j] = b; }
   }
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) {
     const float a = wave_sum(sdb[c]);
     if (lane == 0) red[wave][2 * F + c] = a;
+  }
+  if (DW) {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = dwa[c][j];
+#pragma unroll
+        for (int o = 32; o >= G; o >>= 1) v += __shfl_xor(v, o);
+        if (lane < G) atomicAdd(&sdw[c * F + g * 8 + j], v);
+      }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * F + CMAX; i += blockDim.x) {
@@ -321,6 +390,9 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const Head
     for (int wv = 0; wv < HEAD_THREADS / 64; ++wv) s += red[wv][i];
     if (i < 2 * F) partials[(size_t)blockIdx.x * 2 * F + i] = s;            // [block][2][F]
     else if (i - 2 * F < p.classes) atomicAdd(&dbias[i - 2 * F], s);
+  }
+  if (DW) {
+    for (int i = threadIdx.x; i < p.classes * F; i += blockDim.x) atomicAdd(&dweight[i], sdw[i]);
   }
 }
 
@@ -405,7 +477,8 @@ extern "C" int oct_head_dlogits(const OctHeadDesc* d, const void* y, const float
 extern "C" int oct_head_backward_fused(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
                                        const float* mean, const float* invstd, const float* w, const float* b,
                                        const int64_t* target, const float* dice_coef, float w_ce, const float* dprobs,
-                                       void* dlogits, void* da, float* partials, float* dbias, void* stream) {
+                                       void* dlogits, void* da, float* partials, float* dbias, float* dweight,
+                                       void* stream) {
   int rc = head_check(d, "oct_head_backward_fused");
   if (rc) return rc;
   OCT_CHECK(d->feat == 32, "oct_head_backward_fused: only feat == 32 is fused (got %d); use oct_head_dlogits", d->feat);
@@ -415,16 +488,21 @@ extern "C" int oct_head_backward_fused(const OctHeadDesc* d, const void* y, cons
   p.y = y; p.scale = scale; p.shift = shift; p.w = w; p.b = b; p.target = target; p.dice_coef = dice_coef;
   p.dprobs = dprobs; p.dlogits = dlogits; p.w_ce = w_ce;
   p.n = d->n; p.h = d->h; p.wd = d->w; p.feat = d->feat; p.classes = d->classes;
+  OCT_CHECK(!dweight || d->classes <= 8, "oct_head_backward_fused: the fused weight gradient needs classes <= 8 (got %d)", d->classes);
+  OCT_CHECK(dlogits || dweight, "oct_head_backward_fused: without dlogits the weight gradient must be fused (dweight)");
   const int grid = head_grid(d);
   hipStream_t s = as_stream(stream);
   const int cm = d->classes <= 2 ? 2 : d->classes <= 4 ? 4 : d->classes <= 8 ? 8 : 16;
-#define LAUNCH(T, C) hipLaunchKernelGGL((head_bwd_fused_kernel<T, C>), dim3(grid), dim3(HEAD_THREADS), 0, s, p, mean, \
-                                        invstd, (T*)da, partials, dbias)
-  if (d->dtype == OCT_DT_BF16) {
-    if (cm == 2) LAUNCH(bf16_t, 2); else if (cm == 4) LAUNCH(bf16_t, 4); else if (cm == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 16);
-  } else {
-    if (cm == 2) LAUNCH(float, 2); else if (cm == 4) LAUNCH(float, 4); else if (cm == 8) LAUNCH(float, 8); else LAUNCH(float, 16);
-  }
+#define LAUNCH(T, C, W) hipLaunchKernelGGL((head_bwd_fused_kernel<T, C, W>), dim3(grid), dim3(HEAD_THREADS), 0, s, p, mean, \
+                                           invstd, (T*)da, partials, dbias, dweight)
+#define BYCLS(T, W)                                                                                   \
+  do {                                                                                                \
+    if (cm == 2) LAUNCH(T, 2, W); else if (cm == 4) LAUNCH(T, 4, W); else LAUNCH(T, 8, W);            \
+  } while (0)
+  if (cm == 16) { if (d->dtype == OCT_DT_BF16) LAUNCH(bf16_t, 16, false); else LAUNCH(float, 16, false); }
+  else if (d->dtype == OCT_DT_BF16) { if (dweight) BYCLS(bf16_t, true); else BYCLS(bf16_t, false); }
+  else { if (dweight) BYCLS(float, true); else BYCLS(float, false); }
+#undef BYCLS
 #undef LAUNCH
   return oct_check_launch("head_bwd_fused");
 }

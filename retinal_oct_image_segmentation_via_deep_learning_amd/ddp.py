@@ -72,9 +72,17 @@ def broadcast_parameters(flat_params: torch.Tensor, src: int = 0):
 
 
 class DataParallelTrainer:
-    """model.forward_backward on the local shard -> gradient all-reduce -> fused SGD."""
+    """model.forward_backward on the local shard -> gradient all-reduce -> fused SGD.
 
-    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=0.0, w_ce=1.0, w_dice=0.0):
+    use_graph: the ~150 kernel launches of forward + loss + backward are recorded once into a HIP
+    graph (torch.cuda.CUDAGraph, capture on the stream the C ABI launches on) and replayed per
+    step, which removes the host launch gaps between the short kernels of the deep levels.  The
+    exchange and the one-kernel optimizer step stay outside the graph.  Capture happens on the
+    first step() after `graph_warmup` eager steps (the optimizer's first-step flag and the
+    weight re-packing that follows every update must already be in their steady state)."""
+
+    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=0.0, w_ce=1.0, w_dice=0.0, use_graph=False,
+                 graph_warmup=2):
         from .optim import FusedSGD
         self.model = model
         self.opt = FusedSGD(model.parameters(), lr=lr, momentum=momentum, weight_decay=weight_decay)
@@ -82,9 +90,42 @@ class DataParallelTrainer:
         broadcast_parameters(self.opt.flat_p)
         self.reducer = GradAllReducer(self.opt.flat_g, self.world)
         self.w_ce, self.w_dice = w_ce, w_dice
+        self.use_graph, self.graph_warmup = use_graph, graph_warmup
+        self.graph = None
+        self.graph_error = None
+        self._eager_steps = 0
+        self._sx = self._st = self._loss = None
+
+    def _capture(self, x, target):
+        from . import _lib as L
+        self._sx, self._st = x.clone(), target.clone()
+        L.param_generation[0] += 1          # the recorded forward must contain the weight packing kernels
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                self._loss = self.model.forward_backward(self._sx, self._st, self.w_ce, self.w_dice)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = g
 
     def step(self, x, target):
-        loss = self.model.forward_backward(x, target, self.w_ce, self.w_dice)
+        if self.use_graph and self.graph is None and self.graph_error is None and self._eager_steps >= self.graph_warmup:
+            try:
+                self._capture(x, target)
+            except Exception as e:  # capture is an optimisation: report and keep training eagerly
+                self.graph_error = f"{type(e).__name__}: {e}"
+                self.graph = None
+        if self.graph is not None:
+            if x is not self._sx and x.data_ptr() != self._sx.data_ptr():
+                self._sx.copy_(x, non_blocking=True)
+            if target is not self._st and target.data_ptr() != self._st.data_ptr():
+                self._st.copy_(target, non_blocking=True)
+            self.graph.replay()
+            loss = self._loss
+        else:
+            loss = self.model.forward_backward(x, target, self.w_ce, self.w_dice)
+            self._eager_steps += 1
         self.reducer.start()
         scale = self.reducer.finish()
         self.opt.step(grad_scale=scale)

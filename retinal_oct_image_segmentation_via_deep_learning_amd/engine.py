@@ -442,7 +442,6 @@ class UNetEngine:
         rec = ctx.head_in
         dev = rec.y.device
         hd = L.HeadDesc(self.dt, n, h, w, f, ncls)
-        dl = self._act(n, h, w, ncls, dev)
         if dprobs is not None:
             dprobs = dprobs.to(torch.float32).contiguous()
             tgt, dc, w_ce = None, None, 0.0
@@ -453,20 +452,29 @@ class UNetEngine:
         hsrc = Src(rec.y, f, rec.bn)
         head_partials = None
         hw, hb = P[sp.head_w], P[sp.head_b]
-        bgrad = G[sp.head_b]
+        bgrad, wgrad_t = G[sp.head_b], G[sp.head_w]
+        fused_dw = False
+        dl = None
         if f == 32 and dlogits is None:
-            # fused: dlogits + dA = W^T dlogits + bias gradient + BN-backward partial sums in one pass over y
+            # fused: dlogits + dA = W^T dlogits + bias / weight gradients + BN-backward partial sums in one pass over y
+            fused_dw = ncls <= 8
             if not accumulate:
                 bgrad.zero_()
+                if fused_dw:
+                    wgrad_t.zero_()
+            if not fused_dw:
+                dl = self._act(n, h, w, ncls, dev)
             da = self._act(n, h, w, f, dev)
             nb = lib.oct_head_blocks(C.byref(hd))
             head_partials = torch.empty((nb, 2, f), dtype=torch.float32, device=dev)
             L.check(lib.oct_head_backward_fused(
                 C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(), rec.bn.shift.data_ptr(),
                 rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(), hw.data_ptr(),
-                hb.data_ptr(), L.ptr(tgt), L.ptr(dc), w_ce, L.ptr(dprobs), dl.data_ptr(), da.data_ptr(),
-                head_partials.data_ptr(), bgrad.data_ptr(), _stream()), "oct_head_backward_fused")
+                hb.data_ptr(), L.ptr(tgt), L.ptr(dc), w_ce, L.ptr(dprobs), L.ptr(dl), da.data_ptr(),
+                head_partials.data_ptr(), bgrad.data_ptr(), wgrad_t.data_ptr() if fused_dw else None, _stream()),
+                "oct_head_backward_fused")
         else:
+            dl = self._act(n, h, w, ncls, dev)
             if dlogits is not None:
                 dlf = dlogits.to(torch.float32).contiguous()
                 L.check(lib.oct_nchw_to_nhwc(self.dt, dlf.data_ptr(), dl.data_ptr(), n, ncls, h, w, _stream()),
@@ -481,9 +489,10 @@ class UNetEngine:
             wp = self._pack(sp.head_w, hw, L.PACK_1X1_DGRAD, ncls, f)
             da = self._act(n, h, w, f, dev)
             self._conv(Src(dl, ncls), wp, f, 1, n, h, w, da)
-        # head weight gradient through the generic 1x1 wgrad
-        dwp = self._wgrad(hsrc, dl, ncls, 1, n, h, w)
-        self._unpack(L.PACK_1X1_FPROP, dwp, G[sp.head_w], ncls, f, accumulate)
+        if not fused_dw:
+            # head weight gradient through the generic 1x1 wgrad
+            dwp = self._wgrad(hsrc, dl, ncls, 1, n, h, w)
+            self._unpack(L.PACK_1X1_FPROP, dwp, wgrad_t, ncls, f, accumulate)
         nd = len(sp.dec)
         dskip = [None] * nd
         for di in range(nd - 1, -1, -1):   # last decoder block first
