@@ -115,9 +115,19 @@ def main():
         kinds[k][0] += 1
         kinds[k][1] += s.elapsed_time(e)
     achieved = flops_bscan * args.batch / (conv_ms * 1e-3) / 1e12
+    # HBM bytes per conv launch: PMC counters cannot be read from inside this process, so the figure is
+    # the one tools/traffic_report.py derived from two rocprofv3 --pmc passes over this same command
+    # (profiles/*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of the conv kernels per step), when committed
+    traffic = None
+    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v4_traffic.json")
+    if os.path.exists(tfile) and (args.batch, args.height, args.width, args.features) == (32, 512, 1024, 32):
+        with open(tfile) as fh:
+            conv = json.load(fh).get("conv", {})
+        if conv:
+            traffic = round((conv["read_GB_per_step"] + conv["write_GB_per_step"]) * 1e9 / max(len(prof), 1))
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
         "kernel": "igemm_kernel + wgrad_kernel (conv stack, %d launches/step)" % len(prof),
         "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
         "flop_per_launch": flops_bscan * args.batch / max(len(prof), 1),
