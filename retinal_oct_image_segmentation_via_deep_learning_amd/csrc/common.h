@@ -24,6 +24,9 @@ int oct_check_launch(const char* what);
 // igemm2.hip: pipelined bf16 path for regular shapes (returns 1 taken / 0 not eligible / <0 error)
 int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream);
 int oct_conv_v2_stat_rows(const OctConvDesc* d);
+// igemm3.hip: cooperative 8-MFMA-wave path for Cout % 128 == 0 (same return convention)
+int oct_conv_forward_v3(const OctConvDesc* d, const OctConvArgs* a, void* stream);
+int oct_conv_v3_stat_rows(const OctConvDesc* d);
 int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
 // first.hip: direct kernels for Conv2d(1 -> F)
 int oct_first_stat_rows(const OctConvDesc* d);

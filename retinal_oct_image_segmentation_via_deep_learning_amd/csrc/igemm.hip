@@ -353,6 +353,8 @@ extern "C" int oct_conv_stat_blocks(const OctConvDesc* d) {
   if (!d) return 0;
   const int f1 = oct_first_stat_rows(d);
   if (f1 >= 0) return f1;
+  const int v3 = oct_conv_v3_stat_rows(d);
+  if (v3 >= 0) return v3;
   const int v2 = oct_conv_v2_stat_rows(d);
   if (v2 >= 0) return v2;
   const TileCfg c = pick_cfg(d->cout);
@@ -390,6 +392,7 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
   OCT_CHECK((size_t)d->n * d->h * d->w < (1u << 31), "oct_conv_forward: too many pixels");
   {
     int took = oct_first_fprop(d, a, stream);
+    if (took == 0) took = oct_conv_forward_v3(d, a, stream);
     if (took == 0) took = oct_conv_forward_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
   }
