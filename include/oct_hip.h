@@ -103,6 +103,15 @@ int oct_conv_stat_blocks(const OctConvDesc* d);
  * rows, `taps` taps and `kch` input channels */
 size_t oct_packed_weight_elems(int rows, int taps, int kch);
 int oct_pack_weights(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, void* stream);
+/* The same for up to OCT_PACK_BATCH_MAX weights per launch (all re-packings that follow an optimizer
+ * step in one go); longer lists are split.  Jobs are plain structs read on the host.              */
+#define OCT_PACK_BATCH_MAX 96
+typedef struct OctPackJob {
+  int mode, cout, cin, reserved;
+  const float* w;   /* torch-layout fp32 weight (device) */
+  void* wpacked;    /* oct_packed_weight_elems(...) elements of dtype (device) */
+} OctPackJob;
+int oct_pack_weights_batch(int dtype, int count, const OctPackJob* jobs, void* stream);
 int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void* stream);
 
 /* Weight gradient (replaces the autograd of the same two modules).
@@ -223,12 +232,15 @@ int oct_head_dlogits(const OctHeadDesc* d, const void* y, const float* scale, co
  * partial sums of the masked gradient [oct_head_blocks][2][feat], the bias gradient (atomics into
  * dbias[classes]; caller zeroes) and -- when dweight is not NULL (classes <= 8) -- the weight gradient
  * dW[c][f] = sum dlogits[c]*relu(bn(y))[f] (atomics into dweight[classes][feat], torch layout
- * (Cout,Cin,1,1); caller zeroes), in which case dlogits may be NULL and is then never written.     */
+ * (Cout,Cin,1,1); caller zeroes), in which case dlogits may be NULL and is then never written.
+ * loss_partials (needs target; may be NULL): [oct_head_blocks][OCT_HEAD_LOSS_SLOTS] rows like
+ * oct_head_forward's with only the cross-entropy slot filled -- a training step whose loss has no
+ * Dice term can skip the forward head pass and feed these rows to oct_head_loss_finalize.           */
 int oct_head_backward_fused(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
                             const float* mean, const float* invstd, const float* w, const float* b,
                             const int64_t* target, const float* dice_coef, float w_ce,
                             const float* dprobs, void* dlogits, void* da, float* partials,
-                            float* dbias, float* dweight, void* stream);
+                            float* dbias, float* dweight, double* loss_partials, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / dtype helpers and the optimizer

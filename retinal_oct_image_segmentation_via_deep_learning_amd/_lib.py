@@ -26,6 +26,14 @@ HEAD_LOSS_SLOTS = 2 + 3 * MAX_CLASSES
 c_void_p, c_int, c_size_t, c_float, c_double = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
 
 
+class PackJob(C.Structure):          # struct OctPackJob
+    _fields_ = [("mode", c_int), ("cout", c_int), ("cin", c_int), ("reserved", c_int), ("w", c_void_p),
+                ("wpacked", c_void_p)]
+
+
+PACK_BATCH_MAX = 96
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(k, c_int) for k in (
         "dtype", "n", "h", "w", "c0", "c1", "cout", "taps", "xform0", "xform1", "in_mode", "out_mode",
@@ -61,6 +69,7 @@ SIGNATURES = {
     "oct_conv_stat_blocks": (c_int, [C.POINTER(ConvDesc)]),
     "oct_packed_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "oct_pack_weights": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "oct_pack_weights_batch": (c_int, [c_int, c_int, C.POINTER(PackJob), c_void_p]),
     "oct_conv_forward": (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvArgs), c_void_p]),
     "oct_conv_wgrad": (c_int, [C.POINTER(WgradDesc), C.POINTER(WgradArgs), c_void_p]),
     "oct_unpack_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -88,7 +97,7 @@ SIGNATURES = {
                                  c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "oct_head_backward_fused": (c_int, [C.POINTER(HeadDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "oct_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_nhwc_to_nchw": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_int,

@@ -139,19 +139,23 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_fwd_kernel(const HeadParams
 
 // loss_out[0..2] = total, ce, dice.  dice_coef[0][c] = A_c, dice_coef[1][c] = B_c with
 // d(w_dice*dice)/dp_c = A_c*y_c + B_c
-__global__ void head_loss_finalize_kernel(const double* __restrict__ partials, int nblocks, int classes, double npix,
+__global__ void __launch_bounds__(1024) head_loss_finalize_kernel(const double* __restrict__ partials, int nblocks, int classes, double npix,
                                           float w_ce, float w_dice, float eps, float* loss_out, float* dice_coef) {
   __shared__ double tot[OCT_HEAD_LOSS_SLOTS];
-  __shared__ double part[4][64];
+  __shared__ double part[16][64];
   {
-    // 256 threads: slot = tid % 64, quarter of the block range = tid / 64
-    const int slot = threadIdx.x & 63, qd = threadIdx.x >> 6;
+    // 1024 threads: slot = tid % 64, sixteenth of the block range = tid / 64
+    const int slot = threadIdx.x & 63, seg = threadIdx.x >> 6;
     double s = 0.0;
     if (slot < OCT_HEAD_LOSS_SLOTS)
-      for (int b = qd; b < nblocks; b += 4) s += partials[(size_t)b * OCT_HEAD_LOSS_SLOTS + slot];
-    part[qd][slot] = s;
+      for (int b = seg; b < nblocks; b += 16) s += partials[(size_t)b * OCT_HEAD_LOSS_SLOTS + slot];
+    part[seg][slot] = s;
     __syncthreads();
-    if (threadIdx.x < OCT_HEAD_LOSS_SLOTS) tot[threadIdx.x] = part[0][slot] + part[1][slot] + part[2][slot] + part[3][slot];
+    if (threadIdx.x < OCT_HEAD_LOSS_SLOTS) {
+      double a = 0.0;
+      for (int k = 0; k < 16; ++k) a += part[k][slot];
+      tot[threadIdx.x] = a;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -236,9 +240,11 @@ template <typename T, int CMAX, bool DW>
 __global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const HeadParams p, const float* __restrict__ mean,
                                                                        const float* __restrict__ invstd, T* __restrict__ da_out,
                                                                        float* __restrict__ partials, float* __restrict__ dbias,
-                                                                       float* __restrict__ dweight) {
+                                                                       float* __restrict__ dweight, double* __restrict__ loss_partials) {
   constexpr int F = 32, G = 4, PPB = HEAD_THREADS / G;   // pixels per block per iteration
   __shared__ float red[HEAD_THREADS / 64][2 * F + OCT_MAX_CLASSES];
+  __shared__ double redce[HEAD_THREADS / 64];
+  float ce = 0.f;   // cross-entropy sum of this lane's pixels (g == 0 lanes only; training step without a forward head pass)
   __shared__ float sdw[DW ? CMAX * F : 1];
   const int g = threadIdx.x & 3, slot = threadIdx.x >> 2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -325,6 +331,12 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const Head
       }
 #pragma unroll
       for (int c = 0; c < CMAX; ++c) dl[c] = p.w_ce * (pr[c] - (c == t ? 1.f : 0.f)) * inv_n + pr[c] * (dp[c] - dot);
+      if (loss_partials && g == 0) {
+        float lt = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) lt = (c == t) ? l[c] : lt;
+        ce -= lt - m - lse;
+      }
     }
     // the rest of the backward sees dlogits as stored (activation dtype), like the unfused path
 #pragma unroll
@@ -394,6 +406,16 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const Head
   if (DW) {
     for (int i = threadIdx.x; i < p.classes * F; i += blockDim.x) atomicAdd(&dweight[i], sdw[i]);
   }
+  if (loss_partials) {   // same row layout as head_fwd_kernel: slot 0 = CE sum, the Dice slots stay zero
+    const double v = wave_sum((double)ce);
+    if (lane == 0) redce[wave] = v;
+    __syncthreads();
+    for (int i = threadIdx.x; i < OCT_HEAD_LOSS_SLOTS; i += blockDim.x) {
+      double s = 0.0;
+      if (i == 0) for (int wv = 0; wv < HEAD_THREADS / 64; ++wv) s += redce[wv];
+      loss_partials[(size_t)blockIdx.x * OCT_HEAD_LOSS_SLOTS + i] = s;
+    }
+  }
 }
 
 static int head_grid(const OctHeadDesc* d) {
@@ -452,7 +474,7 @@ extern "C" int oct_head_loss_finalize(const OctHeadDesc* d, const double* loss_p
   int rc = head_check(d, "oct_head_loss_finalize");
   if (rc) return rc;
   OCT_CHECK(loss_partials && loss_out && dice_coef && nblocks > 0, "oct_head_loss_finalize: bad args");
-  hipLaunchKernelGGL(head_loss_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), loss_partials, nblocks,
+  hipLaunchKernelGGL(head_loss_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), loss_partials, nblocks,
                      d->classes, (double)d->n * d->h * d->w, w_ce, w_dice, dice_eps, loss_out, dice_coef);
   return oct_check_launch("head_loss_finalize");
 }
@@ -478,7 +500,7 @@ extern "C" int oct_head_backward_fused(const OctHeadDesc* d, const void* y, cons
                                        const float* mean, const float* invstd, const float* w, const float* b,
                                        const int64_t* target, const float* dice_coef, float w_ce, const float* dprobs,
                                        void* dlogits, void* da, float* partials, float* dbias, float* dweight,
-                                       void* stream) {
+                                       double* loss_partials, void* stream) {
   int rc = head_check(d, "oct_head_backward_fused");
   if (rc) return rc;
   OCT_CHECK(d->feat == 32, "oct_head_backward_fused: only feat == 32 is fused (got %d); use oct_head_dlogits", d->feat);
@@ -490,11 +512,12 @@ extern "C" int oct_head_backward_fused(const OctHeadDesc* d, const void* y, cons
   p.n = d->n; p.h = d->h; p.wd = d->w; p.feat = d->feat; p.classes = d->classes;
   OCT_CHECK(!dweight || d->classes <= 8, "oct_head_backward_fused: the fused weight gradient needs classes <= 8 (got %d)", d->classes);
   OCT_CHECK(dlogits || dweight, "oct_head_backward_fused: without dlogits the weight gradient must be fused (dweight)");
+  OCT_CHECK(!loss_partials || target, "oct_head_backward_fused: loss partials need a target");
   const int grid = head_grid(d);
   hipStream_t s = as_stream(stream);
   const int cm = d->classes <= 2 ? 2 : d->classes <= 4 ? 4 : d->classes <= 8 ? 8 : 16;
 #define LAUNCH(T, C, W) hipLaunchKernelGGL((head_bwd_fused_kernel<T, C, W>), dim3(grid), dim3(HEAD_THREADS), 0, s, p, mean, \
-                                           invstd, (T*)da, partials, dbias, dweight)
+                                           invstd, (T*)da, partials, dbias, dweight, loss_partials)
 #define BYCLS(T, W)                                                                                   \
   do {                                                                                                \
     if (cm == 2) LAUNCH(T, 2, W); else if (cm == 4) LAUNCH(T, 4, W); else LAUNCH(T, 8, W);            \

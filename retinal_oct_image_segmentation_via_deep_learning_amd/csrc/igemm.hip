@@ -341,6 +341,67 @@ extern "C" int oct_pack_weights(int mode, int dtype, const float* w, void* wpack
   return oct_check_launch("pack_weights");
 }
 
+// All re-packings of a training step in ONE launch: the ~43 five-microsecond pack launches that follow
+// every optimizer update were 0.2 ms of the step.  The job table travels in the kernel arguments.
+struct PackJobs { OctPackJob j[OCT_PACK_BATCH_MAX]; };
+template <typename T>
+__global__ void pack_weights_batch_kernel(const PackJobs jobs) {
+  const OctPackJob jb = jobs.j[blockIdx.y];
+  int rows, taps, kch;
+  switch (jb.mode) {
+    case OCT_PACK_CONV_FPROP: rows = jb.cout; taps = 9; kch = jb.cin; break;
+    case OCT_PACK_CONV_DGRAD: rows = jb.cin; taps = 9; kch = jb.cout; break;
+    case OCT_PACK_DECONV_FPROP: rows = 4 * jb.cout; taps = 1; kch = jb.cin; break;
+    case OCT_PACK_DECONV_DGRAD: rows = jb.cin; taps = 1; kch = 4 * jb.cout; break;
+    case OCT_PACK_1X1_DGRAD: rows = jb.cin; taps = 1; kch = jb.cout; break;
+    default: rows = jb.cout; taps = 1; kch = jb.cin; break;
+  }
+  const int nk16 = (kch + 15) / 16;
+  const size_t total = (size_t)((rows + 31) / 32) * taps * nk16 * 512;
+  const float* __restrict__ w = jb.w;
+  T* __restrict__ wp = reinterpret_cast<T*>(jb.wpacked);
+  const int cout = jb.cout, cin = jb.cin, mode = jb.mode;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7;
+    const int lane = (i >> 3) & 63;
+    size_t rest = i >> 9;
+    const int kk = rest % nk16; rest /= nk16;
+    const int tap = rest % taps;
+    const int nb = rest / taps;
+    const int row = nb * 32 + (lane & 31);
+    const int k = kk * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (row < rows && k < kch) {
+      if (mode == OCT_PACK_CONV_FPROP) v = w[((size_t)row * cin + k) * 9 + tap];
+      else if (mode == OCT_PACK_CONV_DGRAD) v = w[((size_t)k * cin + row) * 9 + (8 - tap)];
+      else if (mode == OCT_PACK_DECONV_FPROP) { const int dydx = row / cout, co = row - dydx * cout; v = w[((size_t)k * cout + co) * 4 + dydx]; }
+      else if (mode == OCT_PACK_DECONV_DGRAD) { const int dydx = k / cout, co = k - dydx * cout; v = w[((size_t)row * cout + co) * 4 + dydx]; }
+      else if (mode == OCT_PACK_1X1_DGRAD) v = w[(size_t)k * cin + row];
+      else v = w[(size_t)row * cin + k];
+    }
+    wp[i] = from_f32<T>(v);
+  }
+}
+
+extern "C" int oct_pack_weights_batch(int dtype, int count, const OctPackJob* jobs, void* stream) {
+  OCT_CHECK(count >= 0 && (count == 0 || jobs), "oct_pack_weights_batch: bad arguments");
+  OCT_CHECK(dtype == OCT_DT_BF16 || dtype == OCT_DT_F32, "oct_pack_weights_batch: bad dtype %d", dtype);
+  for (int base = 0; base < count; base += OCT_PACK_BATCH_MAX) {
+    PackJobs pj;
+    const int n = count - base < OCT_PACK_BATCH_MAX ? count - base : OCT_PACK_BATCH_MAX;
+    for (int i = 0; i < n; ++i) {
+      pj.j[i] = jobs[base + i];
+      OCT_CHECK(pj.j[i].mode >= 0 && pj.j[i].mode <= 5 && pj.j[i].cout > 0 && pj.j[i].cin > 0 && pj.j[i].w && pj.j[i].wpacked,
+                "oct_pack_weights_batch: bad job %d", base + i);
+    }
+    if (dtype == OCT_DT_BF16)
+      hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, as_stream(stream), pj);
+    else
+      hipLaunchKernelGGL(pack_weights_batch_kernel<float>, dim3(96, n), dim3(256), 0, as_stream(stream), pj);
+  }
+  return oct_check_launch("pack_weights_batch");
+}
+
 // ---- host dispatch ------------------------------------------------------------------------------
 struct TileCfg { int th; int nt; };
 static TileCfg pick_cfg(int cout) {

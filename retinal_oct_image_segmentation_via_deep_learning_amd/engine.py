@@ -144,6 +144,7 @@ class Ctx:
     dice_coef: torch.Tensor | None = None
     loss: torch.Tensor | None = None
     loss_cfg: tuple = (1.0, 0.0, 1e-7)
+    loss_partials: torch.Tensor | None = None   # set when the loss was deferred to the fused head backward
 
 
 class UNetEngine:
@@ -155,6 +156,7 @@ class UNetEngine:
         self.cin, self.ncls, self.f = self.spec.cin, self.spec.ncls, self.spec.head_feat
         self.set_dtype(dtype)
         self._packed = {}  # (key, mode) -> (version, tensor)
+        self._arena, self._arena_on, self._arena_off, self._arena_short = None, False, 0, False
         self.debug = None  # set to a dict to capture intermediate gradients (tests / probes)
         self.prof = None   # set to a list: (kind, start_event, end_event) around every MFMA launch
 
@@ -165,6 +167,7 @@ class UNetEngine:
         self.dt = L.DT_BF16 if dtype == "bf16" else L.DT_F32
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         self._packed = {}
+        self._pack_plan = {}
 
     # ---- small helpers --------------------------------------------------------------------------
     def _prof_begin(self):
@@ -190,6 +193,7 @@ class UNetEngine:
         hit = self._packed.get((key, mode))
         if hit is not None and hit[0] == ver and hit[2] == wt.data_ptr():
             return hit[1]
+        self._pack_plan[(key, mode)] = (cout, cin)
         rows, taps, kch = {
             L.PACK_CONV_FPROP: (cout, 9, cin), L.PACK_CONV_DGRAD: (cin, 9, cout),
             L.PACK_DECONV_FPROP: (4 * cout, 1, cin), L.PACK_DECONV_DGRAD: (cin, 1, 4 * cout),
@@ -200,6 +204,24 @@ class UNetEngine:
                 "oct_pack_weights")
         self._packed[(key, mode)] = (ver, out, wt.data_ptr())
         return out
+
+    def _prepack(self, P: dict) -> None:
+        """Refresh, in ONE launch, every packed weight a previous step used and the optimizer has since
+        changed (the per-layer `_pack` calls of this step then all hit the cache)."""
+        jobs, news = [], []
+        for (key, mode), (cout, cin) in self._pack_plan.items():
+            wt = P.get(key) if isinstance(key, str) else None
+            hit = self._packed.get((key, mode))
+            if wt is None or hit is None or hit[2] != wt.data_ptr():
+                continue
+            ver = (wt._version, L.param_generation[0])
+            if hit[0] != ver:
+                jobs.append(L.PackJob(mode, cout, cin, 0, wt.data_ptr(), hit[1].data_ptr()))
+                news.append(((key, mode), (ver, hit[1], hit[2])))
+        if jobs:
+            arr = (L.PackJob * len(jobs))(*jobs)
+            L.check(L.lib().oct_pack_weights_batch(self.dt, len(jobs), arr, _stream()), "oct_pack_weights_batch")
+            self._packed.update(news)
 
     def _conv(self, src: Src, wpacked, cout, taps, n, h, w, y0, *, y1=None, split=0, in_mode=L.IN_PLAIN,
               out_mode=L.OUT_PLAIN, bias=None, stats=None):
@@ -225,7 +247,7 @@ class UNetEngine:
     def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None, fused_apply=None):
         """fused_apply = (y, coef, scale, shift): `dy` holds dA and the kernel applies BN backward on load."""
         ktot = src.channels
-        dwp = torch.zeros((taps, cout, ktot), dtype=torch.float32, device=dy.device)
+        dwp = self._dwp_take(taps * cout * ktot, dy.device).view(taps, cout, ktot)
         d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                         L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
                         L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, dy_mode)
@@ -238,6 +260,27 @@ class UNetEngine:
         L.check(L.lib().oct_conv_wgrad(C.byref(d), C.byref(a), _stream()), "oct_conv_wgrad")
         self._prof_end(ev, "wgrad")
         return dwp
+
+    def _dwp_take(self, numel: int, dev) -> torch.Tensor:
+        """Zeroed fp32 scratch for one weight-gradient launch (the kernels accumulate with atomics).  Inside
+        backward() the buffers of a step come out of one arena that is cleared with a single fill."""
+        if self._arena_on:
+            lo = self._arena_off
+            self._arena_off = lo + (numel + 63) // 64 * 64
+            if self._arena is not None and self._arena_off <= self._arena.numel() and self._arena.device == dev:
+                return self._arena[lo:lo + numel]
+            self._arena_short = True
+        return torch.zeros(numel, dtype=torch.float32, device=dev)
+
+    def _arena_begin(self, dev):
+        self._arena_on, self._arena_off, self._arena_short = True, 0, False
+        if self._arena is not None and self._arena.device == dev:
+            self._arena.zero_()
+
+    def _arena_end(self, dev):
+        if self._arena_short or self._arena is None:   # first step (or a larger batch): size it for the next one
+            self._arena = torch.empty(self._arena_off, dtype=torch.float32, device=dev)
+        self._arena_on = False
 
     def _unpack(self, mode, dwp, grad, cout, cin, accumulate):
         L.check(L.lib().oct_unpack_wgrad(mode, dwp.data_ptr(), grad.data_ptr(), cout, cin, int(accumulate),
@@ -282,9 +325,12 @@ class UNetEngine:
         return r2
 
     def forward(self, P: dict, x: torch.Tensor, train: bool, target: torch.Tensor | None = None,
-                loss_cfg=(1.0, 0.0, 1e-7), want_probs=True, want_argmax=False, want_logits=False):
+                loss_cfg=(1.0, 0.0, 1e-7), want_probs=True, want_argmax=False, want_logits=False, defer_loss=False):
         """P: name -> fp32 device tensor with the reference's state_dict keys.
-        Returns (ctx, probs|None, argmax|None, logits|None)."""
+        Returns (ctx, probs|None, argmax|None, logits|None).
+        defer_loss: the caller will run backward() right away and wants no output but the loss; when the
+        loss has no Dice term and the fused head backward applies (32 head features, <= 8 classes) the
+        forward head pass is skipped and backward() computes the cross-entropy while it is there."""
         lib = L.lib()
         if x.dim() != 4 or x.shape[1] != self.cin:
             raise RuntimeError(f"expected input (B,{self.cin},H,W), got {tuple(x.shape)}")
@@ -299,6 +345,8 @@ class UNetEngine:
         if dev.type != "cuda":
             raise L.OctError("the HIP path needs a device tensor (there is no CPU fallback)")
         xf = x.detach().to(torch.float32).contiguous()
+        if train:
+            self._prepack(P)
         ctx = Ctx(n=n, h=h, w=w, loss_cfg=tuple(loss_cfg))
         xt = self._act(n, h, w, self.cin, dev)
         L.check(lib.oct_nchw_to_nhwc(self.dt, xf.data_ptr(), xt.data_ptr(), n, self.cin, h, w, _stream()),
@@ -343,6 +391,13 @@ class UNetEngine:
             target = target.to(device=dev, dtype=torch.int64).contiguous()
             nb = lib.oct_head_blocks(C.byref(hd))
             partials = torch.empty((nb, L.HEAD_LOSS_SLOTS), dtype=torch.float64, device=dev)
+            if (defer_loss and loss_cfg[1] == 0.0 and self.f == 32 and self.ncls <= 8
+                    and not (want_probs or want_argmax or want_logits)):
+                ctx.target = target
+                ctx.loss = torch.empty(3, dtype=torch.float32, device=dev)
+                ctx.dice_coef = torch.zeros(2 * L.MAX_CLASSES, dtype=torch.float32, device=dev)
+                ctx.loss_partials = partials      # filled and finalised by backward()
+                return ctx, None, None, None
         L.check(lib.oct_head_forward(C.byref(hd), prev.y.data_ptr(), prev.bn.scale.data_ptr(),
                                      prev.bn.shift.data_ptr(), P[sp.head_w].data_ptr(),
                                      P[sp.head_b].data_ptr(), L.ptr(target), L.ptr(probs), L.ptr(amax),
@@ -441,6 +496,7 @@ class UNetEngine:
         n, h, w, f, ncls = ctx.n, ctx.h, ctx.w, self.f, self.ncls
         rec = ctx.head_in
         dev = rec.y.device
+        self._arena_begin(dev)
         hd = L.HeadDesc(self.dt, n, h, w, f, ncls)
         if dprobs is not None:
             dprobs = dprobs.to(torch.float32).contiguous()
@@ -471,8 +527,14 @@ class UNetEngine:
                 C.byref(hd), rec.y.data_ptr(), rec.bn.scale.data_ptr(), rec.bn.shift.data_ptr(),
                 rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(), hw.data_ptr(),
                 hb.data_ptr(), L.ptr(tgt), L.ptr(dc), w_ce, L.ptr(dprobs), L.ptr(dl), da.data_ptr(),
-                head_partials.data_ptr(), bgrad.data_ptr(), wgrad_t.data_ptr() if fused_dw else None, _stream()),
+                head_partials.data_ptr(), bgrad.data_ptr(), wgrad_t.data_ptr() if fused_dw else None,
+                L.ptr(ctx.loss_partials) if dprobs is None else None, _stream()),
                 "oct_head_backward_fused")
+            if ctx.loss_partials is not None and dprobs is None:
+                w_ce_, w_dice_, eps_ = ctx.loss_cfg
+                L.check(lib.oct_head_loss_finalize(C.byref(hd), ctx.loss_partials.data_ptr(), ctx.loss_partials.shape[0],
+                                                   w_ce_, w_dice_, eps_, ctx.loss.data_ptr(), ctx.dice_coef.data_ptr(),
+                                                   _stream()), "oct_head_loss_finalize")
         else:
             dl = self._act(n, h, w, ncls, dev)
             if dlogits is not None:
@@ -517,5 +579,6 @@ class UNetEngine:
             # the skip of enc[li] was consumed by decode step nd-1-li
             dpool, _ = self._block_backward(sp.enc[li].name, dskip[nd - 1 - li], dpool, G, accumulate,
                                             need_dx=(li != 0))
+        self._arena_end(dev)
         self._P = self._ctx = None
         return G

@@ -95,12 +95,16 @@ class _EngineNet(nn.Module):
     def forward_backward(self, x, target, w_ce=1.0, w_dice=0.0, dice_eps=1e-7, want_probs=False):
         """Training step without the optimizer: forward, fused CE(+Dice) loss head, full backward.
         Writes `.grad` of every parameter and returns the device tensor [loss, ce, dice]
-        (plus the probabilities when want_probs)."""
+        (plus the probabilities when want_probs).  With w_dice == 0 (and the fused head: 32 head
+        features, <= 8 classes, no probabilities requested) the Dice sums are not accumulated and the
+        third entry is 0: the cross-entropy then comes out of the backward head pass and the forward
+        one is skipped."""
         if not self.training:
             raise RuntimeError("forward_backward needs train() mode (batch statistics)")
         P = self._tensors()
         ectx, probs, _, _ = self._engine.forward(P, x, train=True, target=target,
-                                                 loss_cfg=(w_ce, w_dice, dice_eps), want_probs=want_probs)
+                                                 loss_cfg=(w_ce, w_dice, dice_eps), want_probs=want_probs,
+                                                 defer_loss=True)
         G = {}
         for n, p in self.named_parameters():
             if p.grad is None:

@@ -227,3 +227,32 @@ def test_trainer_hip_graph_replay_matches_eager_steps():
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
     rel = float((res[0][1] - res[1][1]).abs().max() / res[0][1].abs().max())
     assert rel < 5e-3, rel
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_deferred_cross_entropy_in_fused_head_backward(dtype):
+    """forward_backward without a Dice term skips the forward head pass (init_features = 32, <= 8 classes):
+    the loss then comes out of the fused head backward and must equal both the oracle's and the value of
+    the ordinary forward head (`model.loss`)."""
+    from oracle import ref_cpu
+    from retinal_oct_image_segmentation_via_deep_learning_amd import UNet
+    torch.manual_seed(21)
+    model = UNet(1, 8, init_features=32, compute_dtype=dtype).cuda().train()
+    state = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 1, 32, 64, generator=g)
+    t = torch.randint(0, 8, (2, 32, 64), generator=g)
+    loss = model.forward_backward(x.cuda(), t.cuda(), 0.7, 0.0)
+    grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})     # rewind the BN buffers
+    model.cuda()
+    ref_fwd = model.loss(x.cuda(), t.cuda(), 0.7, 0.0)
+    np.testing.assert_allclose(loss[:2].cpu().numpy(), ref_fwd[:2].cpu().numpy(), rtol=1e-5 if dtype == "f32" else 1e-4)
+    assert float(loss[2]) == 0.0 and float(ref_fwd[2]) > 0.0   # Dice sums are not accumulated when its weight is 0
+    if dtype == "f32":
+        net = ref_cpu.OracleUNet(state)
+        _, (rl, rce, _), rg = net.loss_and_grads(x.numpy(), t.numpy(), 0.7, 0.0)
+        np.testing.assert_allclose(loss[0].item(), rl, rtol=2e-5)
+        np.testing.assert_allclose(loss[1].item(), rce, rtol=2e-5)
+        for k, v in grads.items():
+            grad_close(v, rg[k], k, 3e-3)
