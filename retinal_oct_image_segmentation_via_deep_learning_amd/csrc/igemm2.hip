@@ -84,6 +84,12 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   unsigned char* const oscr = smem + 2 * BUFB + (2 * WM * 2 * NT + 4) * 4 + 2 * 1024 * 4;  // 4 waves x 32 px x 80 B
   static_assert((2 * BUFB + (2 * WM * 2 * NT + 4) * 4) % 16 == 0, "scratch must stay 16-B aligned");
   float* const sbias = reinterpret_cast<float*>(oscr + 4 * 32 * 80);   // [cout/4] deconv bias (D2S only)
+  // streamed-weight kernels: BatchNorm partial sums of ALL items of this workgroup, [2][cout]; one row
+  // per workgroup reaches memory instead of one per tile (bn_finalize then reads <= 512 rows, not 16 k)
+  float* const wgacc = sbias + 1024;
+  if (STATS && !WRES) {
+    for (int i = tid; i < 2 * p.cout; i += 512) wgacc[i] = 0.f;
+  }
   {
     const int kx = (p.in_mode == OCT_IN_S2D) ? p.c0 : p.c0 + p.c1;
     for (int i = tid; i < kx; i += 512) {
@@ -213,7 +219,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         if (wave == 4) TRACE(7, nx - 1);
       }
     }
-    if (STATS && WRES) __syncthreads();  // matches the barrier of the final statistics reduction
+    if (STATS) __syncthreads();  // matches the barrier of the final statistics reduction
     return;
   }
 
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         float s = 0.f;
 #pragma unroll
         for (int w_ = 0; w_ < WM; ++w_) s += ws[(w_ * 2 + st) * NT + cl];
-        p.stats[((size_t)pending_tile * 2 + st) * p.cout + pending_nbi * NT + cl] = s;
+        wgacc[st * p.cout + pending_nbi * NT + cl] += s;   // thread i owns (st, cl) for every item: no race
       }
       pending_tile = -1;
     }
@@ -521,15 +527,21 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         for (int w_ = 0; w_ < WM; ++w_) s += ws[(w_ * 2 + st) * NT + cl];
         if (cl < p.cout) p.stats[((size_t)blockIdx.x * 2 + st) * p.cout + cl] = s;
       }
-    } else if (pending_tile >= 0) {
-      const float* ws = wg_stats + (parity ^ 1) * (WM * 2 * NT);
-      for (int i = tid; i < 2 * NT; i += 256) {
-        const int st = i / NT, cl = i - st * NT;
-        float s = 0.f;
+    } else {
+      if (pending_tile >= 0) {
+        const float* ws = wg_stats + (parity ^ 1) * (WM * 2 * NT);
+        for (int i = tid; i < 2 * NT; i += 256) {
+          const int st = i / NT, cl = i - st * NT;
+          float s = 0.f;
 #pragma unroll
-        for (int w_ = 0; w_ < WM; ++w_) s += ws[(w_ * 2 + st) * NT + cl];
-        p.stats[((size_t)pending_tile * 2 + st) * p.cout + pending_nbi * NT + cl] = s;
+          for (int w_ = 0; w_ < WM; ++w_) s += ws[(w_ * 2 + st) * NT + cl];
+          wgacc[st * p.cout + pending_nbi * NT + cl] += s;
+        }
       }
+      // the four MFMA waves of this workgroup wrote disjoint (st, cl) slots with the same thread each time;
+      // make them visible to each other, then one row [2][cout] per workgroup
+      __syncthreads();   // the producer waves join this barrier before they exit
+      for (int i = tid; i < 2 * p.cout; i += 256) p.stats[(size_t)blockIdx.x * 2 * p.cout + i] = wgacc[i];
     }
   }
 }
@@ -567,7 +579,7 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   if (target > pl.nitems) target = pl.nitems;
   pl.per_wg = (pl.nitems + target - 1) / target;
   pl.grid = (pl.nitems + pl.per_wg - 1) / pl.per_wg;
-  pl.stat_rows = pl.wres ? pl.grid : ntiles;
+  pl.stat_rows = pl.grid;   // one row [2][cout] per (persistent) workgroup
   return pl;
 }
 
@@ -579,7 +591,8 @@ int oct_conv_v2_stat_rows(const OctConvDesc* d) {
 template <int WM, int WN, int MF, int NF, bool WRES>
 static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float);
+  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float) +
+                  (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
   if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(512), lds, s, p);
   else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(512), lds, s, p);
 }
