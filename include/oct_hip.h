@@ -143,6 +143,13 @@ int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
  * OCT_PACK_DECONV_FPROP (grad[ci][co][dydx]) or OCT_PACK_1X1_FPROP (grad[co][ci]).
  * accumulate != 0: grad += */
 int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cout, int cin, int accumulate, void* stream);
+/* The same for up to OCT_PACK_BATCH_MAX gradients per launch (a whole backward pass).               */
+typedef struct OctUnpackJob {
+  int mode, cout, cin, accumulate;
+  const float* dwp;   /* [taps][rows][kch] fp32 from oct_conv_wgrad (device) */
+  float* grad;        /* torch-layout fp32 gradient (device) */
+} OctUnpackJob;
+int oct_unpack_wgrad_batch(int count, const OctUnpackJob* jobs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d in training mode (nn.BatchNorm2d, YNet_2022.py:586,598; torch defaults eps=1e-5,

@@ -31,6 +31,11 @@ class PackJob(C.Structure):          # struct OctPackJob
                 ("wpacked", c_void_p)]
 
 
+class UnpackJob(C.Structure):        # struct OctUnpackJob
+    _fields_ = [("mode", c_int), ("cout", c_int), ("cin", c_int), ("accumulate", c_int), ("dwp", c_void_p),
+                ("grad", c_void_p)]
+
+
 PACK_BATCH_MAX = 96
 
 
@@ -73,6 +78,7 @@ SIGNATURES = {
     "oct_conv_forward": (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvArgs), c_void_p]),
     "oct_conv_wgrad": (c_int, [C.POINTER(WgradDesc), C.POINTER(WgradArgs), c_void_p]),
     "oct_unpack_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "oct_unpack_wgrad_batch": (c_int, [c_int, C.POINTER(UnpackJob), c_void_p]),
     "oct_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oct_bn_eval_coeffs": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,

@@ -114,49 +114,38 @@ class UnetUp4(_UnetUpBase):
     _k = 4
 
 
-def weights_init_normal(m):
-    classname = m.__class__.__name__
-    if classname.find("Conv") != -1:
-        init.normal_(m.weight.data, 0.0, 0.02)
-    elif classname.find("Linear") != -1:
-        init.normal_(m.weight.data, 0.0, 0.02)
-    elif classname.find("BatchNorm") != -1:
-        init.normal_(m.weight.data, 1.0, 0.02)
-        init.constant_(m.bias.data, 0.0)
+_CONV_INIT = {
+    "normal": lambda w: init.normal_(w, 0.0, 0.02),
+    "xavier": lambda w: init.xavier_normal_(w, gain=1),
+    "kaiming": lambda w: init.kaiming_normal_(w, a=0, mode="fan_in"),
+}
 
 
-def weights_init_xavier(m):
-    classname = m.__class__.__name__
-    if classname.find("Conv") != -1:
-        init.xavier_normal_(m.weight.data, gain=1)
-    elif classname.find("Linear") != -1:
-        init.xavier_normal_(m.weight.data, gain=1)
-    elif classname.find("BatchNorm") != -1:
-        init.normal_(m.weight.data, 1.0, 0.02)
-        init.constant_(m.bias.data, 0.0)
+def _initializer(kind: str):
+    """The reference selects by class-NAME substring (MGUNet_2021.py:314-342): anything whose name contains
+    'Conv' or 'Linear' gets the weight rule of `kind` (so does ConvTranspose2d -- and a container class
+    such as UnetConv raises AttributeError on `.weight`, there as here); 'BatchNorm' gets N(1, 0.02) / 0."""
+    def fn(m):
+        name = type(m).__name__
+        if "Conv" in name or "Linear" in name:
+            _CONV_INIT[kind](m.weight.data)
+        elif "BatchNorm" in name:
+            init.normal_(m.weight.data, 1.0, 0.02)
+            init.constant_(m.bias.data, 0.0)
+    fn.__name__ = f"weights_init_{kind}"
+    return fn
 
 
-def weights_init_kaiming(m):
-    classname = m.__class__.__name__
-    if classname.find("Conv") != -1:
-        init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
-    elif classname.find("Linear") != -1:
-        init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
-    elif classname.find("BatchNorm") != -1:
-        init.normal_(m.weight.data, 1.0, 0.02)
-        init.constant_(m.bias.data, 0.0)
+weights_init_normal = _initializer("normal")
+weights_init_xavier = _initializer("xavier")
+weights_init_kaiming = _initializer("kaiming")
 
 
 def init_weights(net, init_type="normal"):
-    """MGUNet_2021.py:344-352 (selection by class-name substring, exactly as the reference does)."""
-    if init_type == "normal":
-        net.apply(weights_init_normal)
-    elif init_type == "xavier":
-        net.apply(weights_init_xavier)
-    elif init_type == "kaiming":
-        net.apply(weights_init_kaiming)
-    else:
+    """MGUNet_2021.py:344-352: `net.apply` of the rule; unknown names raise NotImplementedError."""
+    if init_type not in _CONV_INIT:
         raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
+    net.apply({"normal": weights_init_normal, "xavier": weights_init_xavier, "kaiming": weights_init_kaiming}[init_type])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -328,6 +328,8 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   __syncthreads();  // stage 0 is in LDS
   int cur = 0, pending_tile = -1, pending_nbi = 0, parity = 0;
   int item = it0, ch = 0;
+  int tile_c = it0 / p.nblk, nbi_c = it0 - tile_c * p.nblk;   // (tile, channel block) of `item`, kept as counters:
+                                                             // two integer divisions per stage cost ~200 cycles
   for (int sidx = 0; sidx < nstage_pad; ++sidx) {
     if (sidx >= nstage) { __syncthreads(); continue; }   // padded stages: keep the barrier count in step
     // flush the statistics of the previous item (written to wg_stats before the last barrier)
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       pending_tile = -1;
     }
 
-    const int tile = item / p.nblk, nbi = item - tile * p.nblk;
+    const int tile = tile_c, nbi = nbi_c;
     if (ch == 0) {
 #pragma unroll
       for (int m = 0; m < MF; ++m)
@@ -367,7 +369,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         int n_ch = ch + 1, n_item = item;
         if (n_ch == p.nch) { n_ch = 0; n_item = item + 1; }
         if (n_item >= it1) { n_item = item; n_ch = ch; }  // last stage: harmless re-read of valid memory
-        const int n_tile = n_item / p.nblk, n_nbi = n_item - n_tile * p.nblk;
+        const int n_nbi = n_item == item ? nbi : (nbi + 1 == p.nblk ? 0 : nbi + 1);
         wbase_n = p.wp + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512 + lane * 8;
         if (sidx == 0) {
 #pragma unroll
@@ -496,7 +498,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     if (p.trace && blockIdx.x == 0 && wave == 0 && lane == 0 && sidx == nstage - 1) p.trace[2044] = __builtin_amdgcn_s_memrealtime();
 #endif
     cur ^= 1;
-    if (++ch == p.nch) { ch = 0; ++item; }
+    if (++ch == p.nch) {
+      ch = 0; ++item;
+      if (++nbi_c == p.nblk) { nbi_c = 0; ++tile_c; }
+    }
   }
 
   if (DEFER && pend) {  // the last item's fragments

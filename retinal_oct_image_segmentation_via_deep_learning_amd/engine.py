@@ -157,6 +157,7 @@ class UNetEngine:
         self.set_dtype(dtype)
         self._packed = {}  # (key, mode) -> (version, tensor)
         self._arena, self._arena_on, self._arena_off, self._arena_short = None, False, 0, False
+        self._unpack_jobs = []
         self.debug = None  # set to a dict to capture intermediate gradients (tests / probes)
         self.prof = None   # set to a list: (kind, start_event, end_event) around every MFMA launch
 
@@ -274,15 +275,23 @@ class UNetEngine:
 
     def _arena_begin(self, dev):
         self._arena_on, self._arena_off, self._arena_short = True, 0, False
+        self._unpack_jobs = []
         if self._arena is not None and self._arena.device == dev:
             self._arena.zero_()
 
     def _arena_end(self, dev):
+        if self._unpack_jobs:
+            arr = (L.UnpackJob * len(self._unpack_jobs))(*[j[0] for j in self._unpack_jobs])
+            L.check(L.lib().oct_unpack_wgrad_batch(len(self._unpack_jobs), arr, _stream()), "oct_unpack_wgrad_batch")
+            self._unpack_jobs = []
         if self._arena_short or self._arena is None:   # first step (or a larger batch): size it for the next one
             self._arena = torch.empty(self._arena_off, dtype=torch.float32, device=dev)
         self._arena_on = False
 
     def _unpack(self, mode, dwp, grad, cout, cin, accumulate):
+        if self._arena_on:   # inside backward(): all gradients are unpacked by one launch at the end
+            self._unpack_jobs.append((L.UnpackJob(mode, cout, cin, int(accumulate), dwp.data_ptr(), grad.data_ptr()), dwp, grad))
+            return
         L.check(L.lib().oct_unpack_wgrad(mode, dwp.data_ptr(), grad.data_ptr(), cout, cin, int(accumulate),
                                          _stream()), "oct_unpack_wgrad")
 
