@@ -334,8 +334,34 @@ __global__ void gate_fwd_kernel(const T* __restrict__ x, const T* __restrict__ p
     store_vec<T, V>(out + off, v);
   }
 }
-// one thread per pixel loops over the channels: coalescing is poor for small c but the kernel is
-// not on the benchmarked path; the per-pixel sum needs no cross-lane step this way
+// backward: a pixel's c channels are spread over LPP = c/8 consecutive lanes (8-channel vectors, 16-B
+// accesses contiguous across lanes); dp[pix] = sum_c dout*x is a segmented shuffle reduction over those
+// lanes.  Requires c % 8 == 0 and c/8 a power of two <= 64; other channel counts take the scalar kernel.
+template <typename T>
+__global__ void gate_bwd_vec_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ p,
+                                    T* __restrict__ dx, T* __restrict__ dp, size_t npix, int c) {
+  const int lpp = c >> 3;
+  const size_t total = npix * lpp;
+  // the grid-stride keeps whole pixels inside one wave: blockDim (256) is a multiple of lpp
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((total + 63) / 64) * 64; i += (size_t)gridDim.x * blockDim.x) {
+    const bool live = i < total;
+    const size_t pix = live ? i / lpp : 0;
+    const size_t off = pix * c + (live ? (i % lpp) * 8 : 0);
+    float d[8], xv[8];
+    load_vec<T, 8>(dout + off, d);
+    load_vec<T, 8>(x + off, xv);
+    const float pv = to_f32(p[pix]);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc = fmaf(d[j], xv[j], acc); d[j] *= pv; }
+    if (!live) acc = 0.f;
+    for (int o = lpp >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (live) {
+      store_vec<T, 8>(dx + off, d);
+      if ((i % lpp) == 0) dp[pix] = from_f32<T>(acc);
+    }
+  }
+}
 template <typename T>
 __global__ void gate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ p,
                                 T* __restrict__ dx, T* __restrict__ dp, size_t npix, int c) {
@@ -364,8 +390,21 @@ extern "C" int oct_gate_fwd(int dtype, const void* x, const void* p, void* out, 
 extern "C" int oct_gate_bwd(int dtype, const void* dout, const void* x, const void* p, void* dx, void* dp, size_t npix,
                             int c, void* stream) {
   OCT_CHECK(dout && x && p && dx && dp && npix > 0 && c > 0, "oct_gate_bwd: bad args");
-  const int blocks = bk_blocks(npix);
   hipStream_t s = (hipStream_t)stream;
+  const int lpp = c >> 3;
+  if ((c & 7) == 0 && lpp <= 64 && (lpp & (lpp - 1)) == 0) {
+    const int vb = bk_blocks(npix * lpp);
+    if (dtype == OCT_DT_BF16)
+      hipLaunchKernelGGL(gate_bwd_vec_kernel<bf16_t>, dim3(vb), dim3(BK_THREADS), 0, s, (const bf16_t*)dout,
+                         (const bf16_t*)x, (const bf16_t*)p, (bf16_t*)dx, (bf16_t*)dp, npix, c);
+    else if (dtype == OCT_DT_F32)
+      hipLaunchKernelGGL(gate_bwd_vec_kernel<float>, dim3(vb), dim3(BK_THREADS), 0, s, (const float*)dout,
+                         (const float*)x, (const float*)p, (float*)dx, (float*)dp, npix, c);
+    else
+      OCT_CHECK(false, "oct_gate_bwd: bad dtype");
+    return oct_check_launch("gate_bwd");
+  }
+  const int blocks = bk_blocks(npix);
   if (dtype == OCT_DT_BF16)
     hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, dim3(blocks), dim3(BK_THREADS), 0, s, (const bf16_t*)dout,
                        (const bf16_t*)x, (const bf16_t*)p, (bf16_t*)dx, (bf16_t*)dp, npix, c);

@@ -114,3 +114,23 @@ def test_bf16_attunet_tracks_reference(golden_dir):
     assert abs(float(loss.detach()) - float(z["loss"][0])) < 5e-2
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 1e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("c", [4, 8, 24, 64, 512])
+def test_gate_product_backward_all_channel_paths(dt, tol, c):
+    """oct_gate_bwd: vector kernel (c/8 a power of two: segmented shuffle reduction, up to a full wave per
+    pixel) and scalar fallback, against the closed form dx = dout*p, dp = sum_c dout*x."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    torch.manual_seed(c)
+    n, h, w = 2, 9, 13
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    x = torch.randn(n, h, w, c, device="cuda").to(tdt).requires_grad_(True)
+    p = torch.rand(n, h, w, 1, device="cuda").to(tdt).requires_grad_(True)
+    out = ops.Gate.apply(dt, x, p)
+    r = torch.randn_like(out)
+    (out.float() * r.float()).sum().backward()
+    assert (out.float() - x.float() * p.float()).abs().max() < tol
+    dx_ref, dp_ref = r.float() * p.float(), (r.float() * x.float()).sum(-1, keepdim=True)
+    assert (x.grad.float() - dx_ref).abs().max() < tol
+    assert ((p.grad.float() - dp_ref).abs().max() / dp_ref.abs().max()) < tol
