@@ -1,6 +1,7 @@
-// Pipelined, persistent implicit-GEMM 3x3 convolution for bf16 and "regular" shapes
-// (W % 32 == 0, H % 8 == 0, every channel count a multiple of 32) -- the production path of
-// conv3x3 fprop and dgrad.  Irregular shapes and the fp32 parity mode stay on igemm.hip.
+// Pipelined, persistent implicit-GEMM 3x3 convolution for bf16 with every channel count a multiple
+// of 32 -- the production path of conv3x3 fprop and dgrad.  Any H, W: the last tile row / column
+// of a size that is not a multiple of the 8(16) x 32 tile is predicated (loads zeroed, stores and
+// BatchNorm sums masked).  Other channel counts and the fp32 parity mode stay on igemm.hip.
 //
 // Differences to the generic kernel, all driven by the rocprof numbers of round 1:
 //  * persistent workgroups walk a contiguous range of (tile, channel-block) items, so the halo
@@ -51,7 +52,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __device__ __forceinline__ float bf16lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS>
+// RAGGED: H or W is not a multiple of the tile; whole-tile shapes (the benchmark) run the instantiation
+// without any of the predication below (measured: 2-3 % when it was unconditional).
+template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS, bool RAGGED = false>
 __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   static_assert(WM * WN == 4, "four MFMA waves");
   constexpr int TH = WM * MF, TW = 32;
@@ -120,8 +123,13 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       const int pix = pbase + 64 * i;
       const int ly = pix / LW, lx = pix - ly * LW;
       relp[i] = (p.in_mode == OCT_IN_S2D) ? (2 * ly) * (2 * p.w) + 2 * lx : (ly - HALO) * p.w + (lx - HALO);
+      // bottom / right flags are set against the LAST tile row / column of the image: for whole tiles that is
+      // the halo row / column (zero padding), for a ragged size also every local row / column beyond H, W.
+      // They only take effect on tiles of that last row / column (edge bits 1 and 3 below).
+      const int ylast = p.h - (p.tiles_y - 1) * TH + HALO, xlast = p.w - (p.tiles_x - 1) * TW + HALO;
       unsigned c = pix >= NPIX ? 16u : 0u;
-      if (HALO) c |= (ly == 0 ? 1u : 0u) | (ly == LH - 1 ? 2u : 0u) | (lx == 0 ? 4u : 0u) | (lx == LW - 1 ? 8u : 0u);
+      if (HALO) c |= (ly == 0 ? 1u : 0u) | (lx == 0 ? 4u : 0u);
+      c |= (ly >= ylast ? 2u : 0u) | (lx >= xlast ? 8u : 0u);
       code[i] = c;
     }
     auto issue = [&](int sidx, u32x4 (&Rr)[NSLOT], unsigned& vm) {
@@ -308,12 +316,15 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       *reinterpret_cast<u32x2*>(sc + r * 80 + (8 * g + 4 * hh) * 2) = v;   // pixel r, channels 8g+4hh..+3
     }
     const int oy = e_tyi * TH + wm * MF + m;
+    if (RAGGED && oy >= p.h) return;   // ragged last tile row (wave-uniform)
+    const int wlim = (RAGGED && (e_txi + 1) * TW > p.w) ? p.w - e_txi * TW : TW;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int chunk = lane + 64 * k;   // 128 chunks of 16 B: pixel = chunk / 4, part = chunk % 4
       const int px = chunk >> 2, part = chunk & 3;
       const u32x4 v = *reinterpret_cast<const u32x4*>(sc + px * 80 + part * 16);
       const int ox = e_txi * TW + px;
+      if (RAGGED && px >= wlim) continue;   // ragged last tile column
       const size_t pix = (p.out_mode == OCT_OUT_D2S)
                              ? ((size_t)e_img * (2 * p.h) + 2 * oy + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * ox + (dydx & 1)
                              : ((size_t)e_img * p.h + oy) * p.w + ox;
@@ -432,6 +443,19 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       int t = tile;
       const int txi = t % p.tiles_x; t /= p.tiles_x;
       const int tyi = t % p.tiles_y; const int img = t / p.tiles_y;
+      if (RAGGED && STATS && ((tyi + 1) * TH > p.h || (txi + 1) * TW > p.w)) {
+        // ragged last tile: pixels outside the image must not reach the BatchNorm sums (their stores are
+        // skipped anyway).  Zeroed in place, inside this wave-uniform branch: no register cost on whole tiles.
+        const bool col_in = (txi * TW + r) < p.w;   // lane = pixel column
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          const bool in = col_in && (tyi * TH + wm * MF + m) < p.h;
+#pragma unroll
+          for (int q = 0; q < NF; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][q][i] = in ? acc[m][q][i] : 0.f;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
         const int cb0 = (nbi * (NT / 32) + wn * NF + q) * 32;
@@ -564,7 +588,9 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   V2Plan pl = {};
   if (!v2_enabled()) return pl;
   const int cin = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
-  pl.ok = d->dtype == OCT_DT_BF16 && (d->w % 32) == 0 && (d->h % 8) == 0 && (d->c0 % 32) == 0 &&
+  // plain 3x3: any H, W (ragged last tiles are predicated); the deconv modes need whole tiles
+  const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;
+  pl.ok = d->dtype == OCT_DT_BF16 && (whole || d->taps == 9) && (d->c0 % 32) == 0 &&
           (d->c1 % 32) == 0 && (d->cout % 32) == 0 && (d->split % 32) == 0;
   pl.ok = pl.ok && (d->c0 + d->c1) <= 1024 && d->cout <= 4096;   // LDS tables: 2 x 1024 BN coefficients, 1024 bias values
   if (d->taps == 9) pl.ok = pl.ok && d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN;
@@ -578,7 +604,7 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   pl.nblk = d->cout / pl.nt;
   // Cout = 32 (full-resolution, HBM-bound layers): 16-row tiles halve the halo overhead per output pixel
   pl.th = (d->taps == 9 && pl.nt == 32 && (d->h % 16) == 0) ? 16 : 8;
-  const int ntiles = (d->w / 32) * (d->h / pl.th) * d->n;
+  const int ntiles = ((d->w + 31) / 32) * ((d->h + pl.th - 1) / pl.th) * d->n;
   pl.nitems = ntiles * pl.nblk;
   int target = 512;  // 2 workgroups per CU
   if (target > pl.nitems) target = pl.nitems;
@@ -598,7 +624,11 @@ static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
   const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float) +
                   (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
-  if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(512), lds, s, p);
+  const bool ragged = (p.w % 32) != 0 || (p.h % TH) != 0;
+  if (ragged) {
+    if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true, true>), dim3(grid), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false, true>), dim3(grid), dim3(512), lds, s, p);
+  } else if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(512), lds, s, p);
   else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(512), lds, s, p);
 }
 template <int WM, int WN, int MF, int NF>
@@ -625,7 +655,7 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
 #endif
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.cout = d->cout; p.split = d->split;
   p.xf0 = d->xform0; p.xf1 = d->xform1;
-  p.tiles_x = d->w / 32; p.tiles_y = d->h / pl.th; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;
+  p.tiles_x = (d->w + 31) / 32; p.tiles_y = (d->h + pl.th - 1) / pl.th; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;
   const int ktot = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
   p.nch = ktot / 32; p.nk16 = ktot / 16;
   hipStream_t s = as_stream(stream);

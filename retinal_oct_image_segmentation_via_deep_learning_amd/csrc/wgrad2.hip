@@ -45,7 +45,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TAPS, int CB, int IB, int TH>
+template <int TAPS, int CB, int IB, int TH, bool RAGGED>
 __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   constexpr int TW = 32;
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -82,18 +82,22 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     constexpr int SIB = (NPI * 4 + 255) / 256;   // input slots per 32-channel block (256 producer threads)
     constexpr int SDB = (NPD * 4 + 255) / 256;   // dY slots per 32-row block
     constexpr int D = 4;            // stages of global loads in flight per producer thread
-    struct Stage { u32x4 ri[IB][SIB]; u32x4 rd[CB][SDB]; unsigned vm[IB]; };
+    struct Stage { u32x4 ri[IB][SIB]; u32x4 rd[CB][SDB]; unsigned vm[IB]; unsigned vd; };
     Stage R[D];
     // per-slot constants (shared by all blocks): pixel offset from the tile origin + border code
     int reli[SIB], reld[SDB];
-    unsigned code[SIB];
+    unsigned code[SIB], dcode[SDB];   // bits 8-15 / 16-23: local row / column (ragged last tiles), low bits: halo flags
 #pragma unroll
     for (int j = 0; j < SIB; ++j) {
       const int pix = pb + 64 * j;
       const int ly = pix / LW, lx = pix - ly * LW;
       reli[j] = (ly - HALO) * p.w + (lx - HALO);
+      // bottom / right flags against the LAST tile row / column of the image (see igemm2.hip): the halo
+      // row / column for whole tiles, everything beyond H, W for a ragged size
+      const int ylast = p.h - (p.tiles_y - 1) * TH + HALO, xlast = p.w - (p.tiles_x - 1) * TW + HALO;
       unsigned c = pix >= NPI ? 16u : 0u;
-      if (HALO) c |= (ly == 0 ? 1u : 0u) | (ly == LH - 1 ? 2u : 0u) | (lx == 0 ? 4u : 0u) | (lx == LW - 1 ? 8u : 0u);
+      if (HALO) c |= (ly == 0 ? 1u : 0u) | (lx == 0 ? 4u : 0u);
+      c |= (ly >= ylast ? 2u : 0u) | (lx >= xlast ? 8u : 0u);
       code[j] = c;
     }
 #pragma unroll
@@ -101,6 +105,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       const int pix = pb + 64 * j;  // NPD is a multiple of 64: every dY slot is live
       const int ly = pix / TW, lx = pix - ly * TW;
       reld[j] = (p.dy_mode == OCT_IN_S2D) ? (2 * ly) * (2 * p.w) + 2 * lx : ly * p.w + lx;
+      dcode[j] = RAGGED ? ((ly >= p.h - (p.tiles_y - 1) * TH ? 2u : 0u) | (lx >= p.w - (p.tiles_x - 1) * TW ? 8u : 0u)) : 0u;
     }
     auto issue = [&](int s, Stage& S) {
       int t = t0 + s;
@@ -139,8 +144,14 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
           cs = p.cout;
           base = p.dy + origin * cs + row + g * 8;
         }
+        unsigned vd = 0;
 #pragma unroll
-        for (int j = 0; j < SDB; ++j) S.rd[blk][j] = *reinterpret_cast<const u32x4*>(base + __mul24(reld[j], cs));
+        for (int j = 0; j < SDB; ++j) {
+          const bool ok = !RAGGED || (dcode[j] & edge) == 0;   // dY pixels of a ragged last tile beyond the image
+          S.rd[blk][j] = *reinterpret_cast<const u32x4*>(base + (ok ? __mul24(reld[j], cs) : 0));
+          vd |= ok ? (1u << j) : 0u;
+        }
+        if (RAGGED) S.vd = vd;
       }
     };
     auto commit = [&](unsigned char* buf, const Stage& S) {
@@ -180,8 +191,15 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
 #pragma unroll
       for (int blk = 0; blk < CB; ++blk)
 #pragma unroll
-        for (int j = 0; j < SDB; ++j)
-          *reinterpret_cast<u32x4*>(buf + IB * INB + blk * DYB + (pb + 64 * j) * 64 + g * 16) = S.rd[blk][j];
+        for (int j = 0; j < SDB; ++j) {
+          u32x4 v = S.rd[blk][j];
+          if (RAGGED) {
+            const bool live = ((S.vd >> j) & 1u) != 0;   // dY rows / columns of a ragged tile beyond the image: zero
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = live ? v[e] : 0u;
+          }
+          *reinterpret_cast<u32x4*>(buf + IB * INB + blk * DYB + (pb + 64 * j) * 64 + g * 16) = v;
+        }
     };
     const int last = nstage - 1;
 #pragma unroll
@@ -282,32 +300,40 @@ static bool w2_enabled() {
   return on == 1;
 }
 
-template <int TAPS, int CB, int IB, int TH>
-static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
+template <int TAPS, int CB, int IB, int TH, bool RAGGED>
+static void launch_w2r(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   constexpr int halo = TAPS == 9 ? 1 : 0;
   constexpr int stage = IB * (TH + 2 * halo) * (32 + 2 * halo) * 64 + CB * TH * 32 * 64;
   constexpr int lds = 2 * stage + 2 * 32 * IB * (int)sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<TAPS, CB, IB, TH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<TAPS, CB, IB, TH, RAGGED>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.ntiles = p.tiles_x * p.tiles_y * p.n;
+  p.tiles_x = (p.w + 31) / 32; p.tiles_y = (p.h + TH - 1) / TH; p.ntiles = p.tiles_x * p.tiles_y * p.n;
   const int gy = nco / CB, gz = nci / IB;
   int gx = (2 * stage * 2 <= 160 * 1024 ? 512 : 256) / (gy * gz);  // 2 workgroups per CU when LDS allows
   if (gx < 1) gx = 1;
   if (gx > p.ntiles) gx = p.ntiles;
   p.per_wg = (p.ntiles + gx - 1) / gx;
   gx = (p.ntiles + p.per_wg - 1) / p.per_wg;
-  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH>), dim3(gx, gy, gz), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH, RAGGED>), dim3(gx, gy, gz), dim3(512), lds, s, p);
+}
+template <int TAPS, int CB, int IB, int TH>
+static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
+  // whole tiles take the instantiation without the dY validity mask (no register cost on the bench shapes)
+  if ((p.w % 32) == 0 && (p.h % TH) == 0) launch_w2r<TAPS, CB, IB, TH, false>(p, nco, nci, s);
+  else launch_w2r<TAPS, CB, IB, TH, true>(p, nco, nci, s);
 }
 
 // returns 1 when taken, 0 when the shape is not eligible, <0 on error
 int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
   if (!w2_enabled()) return 0;
   const int ktot = d->c0 + d->c1;
-  const bool ok = d->dtype == OCT_DT_BF16 && (d->w % 32) == 0 && (d->h % 8) == 0 && (d->c0 % 32) == 0 &&
+  // plain 3x3 / 1x1: any H, W (ragged last tiles are predicated); the deconv mode needs whole tiles
+  const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;
+  const bool ok = d->dtype == OCT_DT_BF16 && (whole || d->dy_mode == OCT_IN_PLAIN) && (d->c0 % 32) == 0 &&
                   (d->c1 % 32) == 0 && (d->cout % 32) == 0 &&
                   (d->dy_mode == OCT_IN_PLAIN || ((d->cout >> 2) % 32) == 0);
   if (!ok) return 0;

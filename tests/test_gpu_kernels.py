@@ -82,6 +82,10 @@ CONV_SHAPES = [
     (1, 16, 64, 128, 0, 256),  # two channel blocks
     (3, 16, 32, 32, 0, 128),   # two stages per item only
     (1, 48, 32, 96, 32, 128),  # three tile rows: interior tile has no zero border
+    # ragged sizes on the pipelined kernels (H % 8 != 0, W % 32 != 0): last tiles predicated
+    (2, 31, 48, 32, 0, 64),    # AttU_Net's deepest level shape (31 x 48)
+    (1, 62, 96, 32, 32, 32),   # H ragged only, concat, TH = 8 path for Cout = 32
+    (1, 12, 40, 64, 0, 128),   # both ragged, Cout 128
     (2, 16, 64, 1, 0, 32),     # first layer, in_channels = 1: direct stencil kernels (bf16)
     (1, 24, 40, 1, 0, 16),
 ]
