@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   const int t0 = blockIdx.x * p.per_wg, t1 = min(t0 + p.per_wg, p.ntiles);
   if (t0 >= t1) return;
   const int nstage = t1 - t0;
-  const int nstage_pad = (nstage + 3) / 4 * 4;   // producer ring depth D = 4
+  constexpr int DRING = (CB * IB == 4 && TH == 8) ? 2 : 4;   // stages of loads in flight per producer thread (register budget)
+  const int nstage_pad = (nstage + DRING - 1) / DRING * DRING;
 
   // BN scale/shift of this workgroup's input channels in LDS (kept off the in-order vmcnt queue)
   float* const sxf = reinterpret_cast<float*>(smem + 2 * STAGEB);   // [2][32*IB]
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     const int ptid = tid - 256, g = ptid & 3, pb = ptid >> 2;
     constexpr int SIB = (NPI * 4 + 255) / 256;   // input slots per 32-channel block (256 producer threads)
     constexpr int SDB = (NPD * 4 + 255) / 256;   // dY slots per 32-row block
-    constexpr int D = 4;            // stages of global loads in flight per producer thread
+    constexpr int D = DRING;
     struct Stage { u32x4 ri[IB][SIB]; u32x4 rd[CB][SDB]; unsigned vm[IB]; unsigned vd; };
     Stage R[D];
     // per-slot constants (shared by all blocks): pixel offset from the tile origin + border code
@@ -347,7 +348,9 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
   const bool big = (nco % 2 == 0) && (nci % 2 == 0);
   hipStream_t s = as_stream(stream);
   if (d->taps == 9) {
-    if (big) launch_w2<9, 2, 2, 4>(p, nco, nci, s); else launch_w2<9, 1, 1, 8>(p, nco, nci, s);
+    // 64 x 64 channel blocks: 8-row tiles (halo overhead 10/8 instead of 6/4 on the staged input, half the
+    // barriers; the two 76-KB stage buffers fill the LDS and the producer ring drops to 2 stages): -5 %
+    if (big) launch_w2<9, 2, 2, 8>(p, nco, nci, s); else launch_w2<9, 1, 1, 8>(p, nco, nci, s);
   } else {
     if (big) launch_w2<1, 2, 2, 4>(p, nco, nci, s); else launch_w2<1, 1, 1, 8>(p, nco, nci, s);
   }
