@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   const int t0 = blockIdx.x * p.per_wg, t1 = min(t0 + p.per_wg, p.ntiles);
   if (t0 >= t1) return;
   const int nstage = t1 - t0;
-  constexpr int DRING = (CB * IB == 4 && TH == 8) ? 2 : 4;   // stages of loads in flight per producer thread (register budget)
+  constexpr int DRING = ((CB * IB == 4 && TH == 8) || TH == 16) ? 2 : 4;   // stages of loads in flight per producer thread (register budget)
   const int nstage_pad = (nstage + DRING - 1) / DRING * DRING;
 
   // BN scale/shift of this workgroup's input channels in LDS (kept off the in-order vmcnt queue)
@@ -350,7 +350,8 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
   if (d->taps == 9) {
     // 64 x 64 channel blocks: 8-row tiles (halo overhead 10/8 instead of 6/4 on the staged input, half the
     // barriers; the two 76-KB stage buffers fill the LDS and the producer ring drops to 2 stages): -5 %
-    if (big) launch_w2<9, 2, 2, 8>(p, nco, nci, s); else launch_w2<9, 1, 1, 8>(p, nco, nci, s);
+    // 32 x 32 channel blocks (the 32-channel full-resolution layers): 16-row tiles, halo overhead 18/16 -- -6 %
+    if (big) launch_w2<9, 2, 2, 8>(p, nco, nci, s); else launch_w2<9, 1, 1, 16>(p, nco, nci, s);
   } else {
     if (big) launch_w2<1, 2, 2, 4>(p, nco, nci, s); else launch_w2<1, 1, 1, 8>(p, nco, nci, s);
   }
