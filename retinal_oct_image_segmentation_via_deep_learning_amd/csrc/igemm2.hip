@@ -603,7 +603,9 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   pl.wres = (d->taps == 9) && (cin == 32) && (d->cout == pl.nt) && pl.nt <= 64;
   pl.nblk = d->cout / pl.nt;
   // Cout = 32 (full-resolution, HBM-bound layers): 16-row tiles halve the halo overhead per output pixel
-  pl.th = (d->taps == 9 && pl.nt == 32 && (d->h % 16) == 0) ? 16 : 8;
+  // 16-row tiles: Cout = 32 always; Cout = 64 with streamed weights in fprop (each wave then owns 4 rows x 64
+  // channels: half the LDS reads per MFMA, halo overhead 18/16) -- measured -2 % on fprop, neutral to worse on dgrad
+  pl.th = (d->taps == 9 && (pl.nt == 32 || (pl.nt == 64 && d->want_stats && !pl.wres)) && (d->h % 16) == 0) ? 16 : 8;
   const int ntiles = ((d->w + 31) / 32) * ((d->h + pl.th - 1) / pl.th) * d->n;
   pl.nitems = ntiles * pl.nblk;
   int target = 256;  // one persistent workgroup per CU (only one fits the LDS); 512 measured 2 % slower on dgrad, 1024 4 %
@@ -667,6 +669,8 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
     if (pl.wres) launch_v2<4, 1, 4, 1, true>(p, pl.grid, s); else launch_v2<4, 1, 4, 1, false>(p, pl.grid, s);
   } else if (pl.nt == 32) {
     if (pl.wres) launch_v2<4, 1, 2, 1, true>(p, pl.grid, s); else launch_v2<4, 1, 2, 1, false>(p, pl.grid, s);
+  } else if (pl.nt == 64 && !pl.wres && pl.th == 16) {
+    launch_v2<4, 1, 4, 2, false>(p, pl.grid, s);
   } else if (pl.nt == 64) {
     if (pl.wres) launch_v2<2, 2, 4, 1, true>(p, pl.grid, s); else launch_v2<2, 2, 4, 1, false>(p, pl.grid, s);
   } else {

@@ -353,7 +353,7 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
     // 32 x 32 channel blocks (the 32-channel full-resolution layers): 16-row tiles, halo overhead 18/16 -- -6 %
     if (big) launch_w2<9, 2, 2, 8>(p, nco, nci, s); else launch_w2<9, 1, 1, 16>(p, nco, nci, s);
   } else {
-    if (big) launch_w2<1, 2, 2, 4>(p, nco, nci, s); else launch_w2<1, 1, 1, 8>(p, nco, nci, s);
+    if (big) launch_w2<1, 2, 2, 8>(p, nco, nci, s); else launch_w2<1, 1, 1, 8>(p, nco, nci, s);   // 8 rows: -14 % vs 4
   }
   int rc = oct_check_launch("wgrad2");
   return rc ? rc : 1;
