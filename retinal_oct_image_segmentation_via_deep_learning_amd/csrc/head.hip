@@ -5,7 +5,13 @@
 // lanes write consecutive addresses.  Loss sums are reduced wave -> workgroup -> fp64 partials.
 #include "common.h"
 
+#include <stdlib.h>
+
 #define HEAD_THREADS 256
+int oct_head_backward_mfma(const OctHeadDesc* d, const void* y, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, const float* w, const float* b, const int64_t* target,
+                           const float* dice_coef, float w_ce, void* da, float* partials, float* dbias, float* dweight,
+                           double* loss_partials, int grid, void* stream);
 #define HEAD_MAX_FEAT 128
 
 struct HeadParams {
@@ -513,6 +519,14 @@ extern "C" int oct_head_backward_fused(const OctHeadDesc* d, const void* y, cons
   OCT_CHECK(!dweight || d->classes <= 8, "oct_head_backward_fused: the fused weight gradient needs classes <= 8 (got %d)", d->classes);
   OCT_CHECK(dlogits || dweight, "oct_head_backward_fused: without dlogits the weight gradient must be fused (dweight)");
   OCT_CHECK(!loss_partials || target, "oct_head_backward_fused: loss partials need a target");
+  {
+    // matrix-pipe formulation (head_mfma.hip): bf16, loss from labels, fused dW, dlogits not requested
+    static int mfma_on = -1;
+    if (mfma_on < 0) { const char* e = getenv("OCT_HEAD_MFMA"); mfma_on = (e && e[0] == '0') ? 0 : 1; }
+    if (mfma_on && d->dtype == OCT_DT_BF16 && d->classes <= 8 && target && !dprobs && dweight && !dlogits)
+      return oct_head_backward_mfma(d, y, scale, shift, mean, invstd, w, b, target, dice_coef, w_ce, da, partials, dbias,
+                                    dweight, loss_partials, head_grid(d), stream);
+  }
   const int grid = head_grid(d);
   hipStream_t s = as_stream(stream);
   const int cm = d->classes <= 2 ? 2 : d->classes <= 4 ? 4 : d->classes <= 8 ? 8 : 16;
