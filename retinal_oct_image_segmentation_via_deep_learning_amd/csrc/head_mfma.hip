@@ -56,7 +56,7 @@ __device__ __forceinline__ float hm_hi(unsigned u) { return __uint_as_float(u & 
 __device__ __forceinline__ float hm_other(float v) { return __shfl_xor(v, 32); }            // lane r <-> lane r + 32
 __device__ __forceinline__ unsigned hm_other(unsigned v) { return (unsigned)__shfl_xor((int)v, 32); }
 
-__global__ void __launch_bounds__(HM_THREADS) head_bwd_mfma_kernel(const HeadMfmaParams p) {
+__global__ void __launch_bounds__(HM_THREADS, 2) head_bwd_mfma_kernel(const HeadMfmaParams p) {
   typedef Mma<bf16_t> M;
   typedef M::Frag Frag;
   constexpr int F = 32;
