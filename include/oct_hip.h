@@ -242,7 +242,9 @@ int oct_head_dlogits(const OctHeadDesc* d, const void* y, const float* scale, co
  * (Cout,Cin,1,1); caller zeroes), in which case dlogits may be NULL and is then never written.
  * loss_partials (needs target; may be NULL): [oct_head_blocks][OCT_HEAD_LOSS_SLOTS] rows like
  * oct_head_forward's with only the cross-entropy slot filled -- a training step whose loss has no
- * Dice term can skip the forward head pass and feed these rows to oct_head_loss_finalize.           */
+ * Dice term can skip the forward head pass and feed these rows to oct_head_loss_finalize.
+ * bf16 with classes <= 8, a target, dweight and no dlogits runs on the matrix pipe (head_mfma.hip);
+ * every other combination on the vector kernel (head.hip).  OCT_HEAD_MFMA=0 forces the latter.     */
 int oct_head_backward_fused(const OctHeadDesc* d, const void* y, const float* scale, const float* shift,
                             const float* mean, const float* invstd, const float* w, const float* b,
                             const int64_t* target, const float* dice_coef, float w_ce,
