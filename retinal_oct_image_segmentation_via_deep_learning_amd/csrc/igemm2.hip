@@ -73,7 +73,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   unsigned char* const buf0 = smem;
   float* const wg_stats = reinterpret_cast<float*>(smem + 2 * BUFB);  // [2 parity][WM][2][NT]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: everything derived from it stays scalar
+  // the 3x3 kernels only run plain -> plain (plan_v2); the deconv modes belong to the 1x1 instantiations
+  const bool s2d = TAPS == 1 && p.in_mode == OCT_IN_S2D;
+  const bool d2s = TAPS == 1 && p.out_mode == OCT_OUT_D2S;
   const int it0 = blockIdx.x * p.per_wg;
   const int it1 = min(it0 + p.per_wg, p.nitems);
   if (it0 >= it1) return;
@@ -94,14 +98,14 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     for (int i = tid; i < 2 * p.cout; i += 512) wgacc[i] = 0.f;
   }
   {
-    const int kx = (p.in_mode == OCT_IN_S2D) ? p.c0 : p.c0 + p.c1;
+    const int kx = s2d ? p.c0 : p.c0 + p.c1;
     for (int i = tid; i < kx; i += 512) {
       const bool first = i < p.c0;
       const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
       sxf[i] = xf ? (first ? p.sc0[i] : p.sc1[i - p.c0]) : 1.f;
       sxf[kx + i] = xf ? (first ? p.sh0[i] : p.sh1[i - p.c0]) : 0.f;
     }
-    if (p.out_mode == OCT_OUT_D2S && p.bias)
+    if (d2s && p.bias)
       for (int i = tid; i < (p.cout >> 2); i += 512) sbias[i] = p.bias[i];
   }
   __syncthreads();
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     for (int i = 0; i < NSLOT; ++i) {
       const int pix = pbase + 64 * i;
       const int ly = pix / LW, lx = pix - ly * LW;
-      relp[i] = (p.in_mode == OCT_IN_S2D) ? (2 * ly) * (2 * p.w) + 2 * lx : (ly - HALO) * p.w + (lx - HALO);
+      relp[i] = s2d ? (2 * ly) * (2 * p.w) + 2 * lx : ly * p.w + lx;   // relative to the halo corner: never negative
       // bottom / right flags are set against the LAST tile row / column of the image: for whole tiles that is
       // the halo row / column (zero padding), for a ragged size also every local row / column beyond H, W.
       // They only take effect on tiles of that last row / column (edge bits 1 and 3 below).
@@ -132,18 +136,36 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       c |= (ly >= ylast ? 2u : 0u) | (lx >= xlast ? 8u : 0u);
       code[i] = c;
     }
-    auto issue = [&](int sidx, u32x4 (&Rr)[NSLOT], unsigned& vm) {
-      const int item = it0 + sidx / p.nch, ch = sidx - (sidx / p.nch) * p.nch;
-      int t = item / p.nblk;
-      const int txi = t % p.tiles_x; t /= p.tiles_x;
-      const int tyi = t % p.tiles_y; const int img = t / p.tiles_y;
+    // Stages are issued and committed strictly in order (0, 1, 2, ... clamped at the last one), so the
+    // (chunk, tile x, tile y, image) of the next stage are counters: the five integer divisions they replace
+    // were ~150 scalar instructions per stage on the producer's critical path.
+    const int last = nstage - 1;
+    int i_sidx = 0, i_ch = 0, i_nbi, i_txi, i_tyi, i_img, c_sidx = 0, c_ch = 0;
+    {
+      int t = it0 / p.nblk;
+      i_nbi = it0 - t * p.nblk;
+      i_txi = t % p.tiles_x; t /= p.tiles_x;
+      i_tyi = t % p.tiles_y; i_img = t / p.tiles_y;
+    }
+    auto issue = [&](u32x4 (&Rr)[NSLOT], unsigned& vm) {
+      const int ch = i_ch, txi = i_txi, tyi = i_tyi, img = i_img;
+      if (i_sidx < last) {
+        ++i_sidx;
+        if (++i_ch == p.nch) {
+          i_ch = 0;
+          if (++i_nbi == p.nblk) {
+            i_nbi = 0;
+            if (++i_txi == p.tiles_x) { i_txi = 0; if (++i_tyi == p.tiles_y) { i_tyi = 0; ++i_img; } }
+          }
+        }
+      }
       const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
                             (txi == p.tiles_x - 1 ? 8u : 0u);
       const size_t origin = ((size_t)img * p.h + tyi * TH) * p.w + txi * TW;
-      const bool second = p.in_mode == OCT_IN_PLAIN && ch * 32 >= p.c0;  // uniform: a 32-channel chunk lies in one source
+      const bool second = !s2d && ch * 32 >= p.c0;  // uniform: a 32-channel chunk lies in one source
       const int cs = second ? p.c1 : p.c0;
       const bf16_t* base;
-      if (p.in_mode == OCT_IN_S2D) {  // k = (dy*2+dx)*C + c of the 2H x 2W tensor
+      if (s2d) {  // k = (dy*2+dx)*C + c of the 2H x 2W tensor
         const int dydx = (ch * 32) / p.c0, cc = ch * 32 - dydx * p.c0;
         const size_t o2 = ((size_t)img * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
         base = p.x0 + o2 * p.c0 + cc + grp * 8;
@@ -153,25 +175,30 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // Loads are UNCONDITIONAL (out-of-image / dead slots re-read the tile origin and are zeroed at
       // commit): a load under a divergent branch makes hipcc fall back to s_waitcnt vmcnt(0) at every
       // use, which drains the whole multi-stage prefetch ring.
+      // scalar 64-bit base (the tile's halo corner; it may lie outside the tensor, dead slots read the tile
+      // origin instead) + unsigned 32-bit lane offset: one global_load with an SGPR base per slot
+      const unsigned cs2 = 2u * (unsigned)cs, safe = (unsigned)(HALO * (p.w + 1)) * cs2;
+      const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - safe;
       vm = 0;
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
         const bool ok = (code[i] & edge) == 0;
-        Rr[i] = *reinterpret_cast<const u32x4*>(base + (ok ? __mul24(relp[i], cs) : 0));
+        Rr[i] = *reinterpret_cast<const u32x4*>(hb + (ok ? __umul24((unsigned)relp[i], cs2) : safe));
         vm |= ok ? (1u << i) : 0u;
       }
     };
-    auto commit = [&](int sidx, unsigned char* buf, const u32x4 (&Rr)[NSLOT], unsigned vm) {
-      const int ch = sidx - (sidx / p.nch) * p.nch;
+    auto commit = [&](unsigned char* buf, const u32x4 (&Rr)[NSLOT], unsigned vm) {
+      const int ch = c_ch;
+      if (c_sidx < last) { ++c_sidx; if (++c_ch == p.nch) c_ch = 0; }
       int cg = ch * 32 + grp * 8;
-      if (p.in_mode == OCT_IN_S2D) cg -= ((ch * 32) / p.c0) * p.c0;
+      if (s2d) cg -= ((ch * 32) / p.c0) * p.c0;
       // wave-uniform on purpose (a 32-channel chunk lies in one source): a per-lane select between the
       // two kernel arguments would become a VECTOR load + s_waitcnt vmcnt(0) in the middle of the ring
-      const bool first = p.in_mode == OCT_IN_S2D || ch * 32 < p.c0;
+      const bool first = s2d || ch * 32 < p.c0;
       const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
       float s[8], b[8];
       if (xf) {
-        const int kx = (p.in_mode == OCT_IN_S2D) ? p.c0 : p.c0 + p.c1;
+        const int kx = s2d ? p.c0 : p.c0 + p.c1;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sxf + cg), s1 = *reinterpret_cast<const f32x4*>(sxf + cg + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(sxf + kx + cg), b1 = *reinterpret_cast<const f32x4*>(sxf + kx + cg + 4);
 #pragma unroll
@@ -203,11 +230,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         }
       }
     };
-    const int last = nstage - 1;
 #pragma unroll
-    for (int j = 0; j < D; ++j) issue(min(j, last), R[j], vmask[j]);   // stages past the end re-read the last one
-    commit(0, buf0, R[0], vmask[0]);
-    issue(min(D, last), R[0], vmask[0]);
+    for (int j = 0; j < D; ++j) issue(R[j], vmask[j]);   // stages past the end re-read the last one
+    commit(buf0, R[0], vmask[0]);
+    issue(R[0], vmask[0]);
     __syncthreads();
     // Stage k lives in ring slot k % D; while the MFMA waves work on stage cs, stage cs+1 is written to
     // the other LDS buffer and its slot is refilled with the loads of stage cs+1+D.  The body is
@@ -219,9 +245,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       for (int j = 0; j < D; ++j) {
         const int nx = s0 + j + 1;
         if (wave == 4) TRACE(4, nx - 1);
-        commit(min(nx, last), buf0 + (nx & 1) * BUFB, R[(j + 1) % D], vmask[(j + 1) % D]);
+        commit(buf0 + (nx & 1) * BUFB, R[(j + 1) % D], vmask[(j + 1) % D]);
         if (wave == 4) TRACE(5, nx - 1);
-        issue(min(nx + D, last), R[(j + 1) % D], vmask[(j + 1) % D]);
+        issue(R[(j + 1) % D], vmask[(j + 1) % D]);
         if (wave == 4) TRACE(6, nx - 1);
         __syncthreads();
         if (wave == 4) TRACE(7, nx - 1);
@@ -303,7 +329,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     const int pm = DEFER ? m : 0, pq = DEFER ? q : 0;
     const int cb0 = (e_nbi * (NT / 32) + wn * NF + q) * 32;
     bf16_t* dst; int cd, co, dydx = 0;
-    if (p.out_mode == OCT_OUT_D2S) { cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0; }
+    if (d2s) { cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0; }
     else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
     else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
     // transpose the 32 pixel x 32 channel fragment through a wave-private LDS scratch so that
@@ -318,21 +344,19 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     const int oy = e_tyi * TH + wm * MF + m;
     if (RAGGED && oy >= p.h) return;   // ragged last tile row (wave-uniform)
     const int wlim = (RAGGED && (e_txi + 1) * TW > p.w) ? p.w - e_txi * TW : TW;
+    // address = wave-uniform 64-bit base of the fragment's first pixel (scalar ALU) + a 32-bit lane offset:
+    // the per-lane 64-bit multiplies this replaces cost more issue slots than the stores themselves
+    const size_t pix0 = d2s ? ((size_t)e_img * (2 * p.h) + 2 * oy + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * (e_txi * TW) + (dydx & 1)
+                            : ((size_t)e_img * p.h + oy) * p.w + e_txi * TW;
+    unsigned char* const fb = reinterpret_cast<unsigned char*>(dst + pix0 * cd + co);
+    const unsigned pstep = (d2s ? 4u : 2u) * (unsigned)cd;   // bytes between horizontally adjacent output pixels
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int chunk = lane + 64 * k;   // 128 chunks of 16 B: pixel = chunk / 4, part = chunk % 4
       const int px = chunk >> 2, part = chunk & 3;
       const u32x4 v = *reinterpret_cast<const u32x4*>(sc + px * 80 + part * 16);
-      const int ox = e_txi * TW + px;
       if (RAGGED && px >= wlim) continue;   // ragged last tile column
-      const size_t pix = (p.out_mode == OCT_OUT_D2S)
-                             ? ((size_t)e_img * (2 * p.h) + 2 * oy + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * ox + (dydx & 1)
-                             : ((size_t)e_img * p.h + oy) * p.w + ox;
-#ifndef ABL_NO_STORE
-      *reinterpret_cast<u32x4*>(dst + pix * cd + co + part * 8) = v;
-#else
-      if (v[0] == 0x12345678u && v[1] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(dst + pix * cd + co + part * 8) = v;
-#endif
+      *reinterpret_cast<u32x4*>(fb + (__umul24((unsigned)px, pstep) + (unsigned)part * 16u)) = v;
     }
   };
 
@@ -341,6 +365,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   int item = it0, ch = 0;
   int tile_c = it0 / p.nblk, nbi_c = it0 - tile_c * p.nblk;   // (tile, channel block) of `item`, kept as counters:
                                                              // two integer divisions per stage cost ~200 cycles
+  int txi_c = tile_c % p.tiles_x, tyi_c = (tile_c / p.tiles_x) % p.tiles_y, img_c = tile_c / (p.tiles_x * p.tiles_y);
   for (int sidx = 0; sidx < nstage_pad; ++sidx) {
     if (sidx >= nstage) { __syncthreads(); continue; }   // padded stages: keep the barrier count in step
     // flush the statistics of the previous item (written to wg_stats before the last barrier)
@@ -440,9 +465,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     if (wave == 0) TRACE(1, sidx);
     // ---- epilogue of an item: NHWC stores, BN sums ----
     if (ch == p.nch - 1) {
-      int t = tile;
-      const int txi = t % p.tiles_x; t /= p.tiles_x;
-      const int tyi = t % p.tiles_y; const int img = t / p.tiles_y;
+      const int txi = txi_c, tyi = tyi_c, img = img_c;
       if (RAGGED && STATS && ((tyi + 1) * TH > p.h || (txi + 1) * TW > p.w)) {
         // ragged last tile: pixels outside the image must not reach the BatchNorm sums (their stores are
         // skipped anyway).  Zeroed in place, inside this wave-uniform branch: no register cost on whole tiles.
@@ -460,30 +483,36 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       for (int q = 0; q < NF; ++q) {
         const int cb0 = (nbi * (NT / 32) + wn * NF + q) * 32;
         bf16_t* dst; int cd, co, dydx = 0;
-        if (p.out_mode == OCT_OUT_D2S) {
+        if (d2s) {
           cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0;
         } else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
         else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
         // deconv bias from LDS (staged at kernel start): a global load here would put a vmcnt(0) --
         // i.e. a drain of the weight ring and of all earlier output stores -- into every epilogue
+        const bool has_bias = d2s && p.bias != nullptr;   // compile-time false in the 3x3 kernels
         float bv[16];
-        if (p.out_mode == OCT_OUT_D2S && p.bias) {
+        if (has_bias) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + co + 8 * g + 4 * hh);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[4 * g + j] = b4[j];
           }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) bv[i] = 0.f;
         }
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
+          if (has_bias) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            packed[DEFER ? m : 0][DEFER ? q : 0][2 * g] = pack_bf16x2(acc[m][q][4 * g] + bv[4 * g], acc[m][q][4 * g + 1] + bv[4 * g + 1]);
-            packed[DEFER ? m : 0][DEFER ? q : 0][2 * g + 1] = pack_bf16x2(acc[m][q][4 * g + 2] + bv[4 * g + 2], acc[m][q][4 * g + 3] + bv[4 * g + 3]);
+            for (int g = 0; g < 4; ++g) {
+              packed[DEFER ? m : 0][DEFER ? q : 0][2 * g] = pack_bf16x2(acc[m][q][4 * g] + bv[4 * g], acc[m][q][4 * g + 1] + bv[4 * g + 1]);
+              packed[DEFER ? m : 0][DEFER ? q : 0][2 * g + 1] = pack_bf16x2(acc[m][q][4 * g + 2] + bv[4 * g + 2], acc[m][q][4 * g + 3] + bv[4 * g + 3]);
+            }
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              packed[DEFER ? m : 0][DEFER ? q : 0][2 * g] = pack_bf16x2(acc[m][q][4 * g], acc[m][q][4 * g + 1]);
+              packed[DEFER ? m : 0][DEFER ? q : 0][2 * g + 1] = pack_bf16x2(acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]);
+            }
           }
           if (!DEFER) { e_img = img; e_tyi = tyi; e_txi = txi; e_nbi = nbi; store_frag(m, q); }
           if (STATS) {
@@ -524,7 +553,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     cur ^= 1;
     if (++ch == p.nch) {
       ch = 0; ++item;
-      if (++nbi_c == p.nblk) { nbi_c = 0; ++tile_c; }
+      if (++nbi_c == p.nblk) {
+        nbi_c = 0; ++tile_c;
+        if (++txi_c == p.tiles_x) { txi_c = 0; if (++tyi_c == p.tiles_y) { tyi_c = 0; ++img_c; } }
+      }
     }
   }
 
