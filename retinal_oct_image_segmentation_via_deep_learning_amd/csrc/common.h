@@ -65,6 +65,11 @@ template <> struct Mma<bf16_t> {
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
+  // first step of an accumulation: C is the inline constant 0, the accumulator needs no zero fill
+  static __device__ __forceinline__ void mma0(f32x16& acc, const Frag& a, const Frag& b) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
+  }
   static __device__ __forceinline__ Frag load(const void* p) { return *reinterpret_cast<const Frag*>(p); }
   static __device__ __forceinline__ Frag zero() {
     Frag f;

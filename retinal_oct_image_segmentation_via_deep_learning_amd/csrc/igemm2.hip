@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   if (wave >= 4) {
     // =============================== producer waves (4) ===============================
     // global -> registers (issued two stages ahead) -> BN+ReLU -> LDS halo tile of the next stage
-    if (WRES) __builtin_amdgcn_s_setprio(2);
+    // (no raised priority for the producers: the MFMA waves interleave their epilogue with the matrix steps)
     const int ptid = tid - 256, grp = ptid & 3, pbase = ptid >> 2;
     constexpr int D = 4;            // stages of global loads in flight per producer thread
     u32x4 R[D][NSLOT];
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // ================================= MFMA waves (4) =================================
   // each SIMD hosts one MFMA wave and one producer wave: the MFMA wave must win issue arbitration
   // against the partner's VALU-dense staging code (static priority, MI355X_MICROARCH.md item 4)
-  if (!WRES) __builtin_amdgcn_s_setprio(3);   // resident-weight (Cout <= 64, Cin = 32) kernels are producer-bound
+  __builtin_amdgcn_s_setprio(3);
   const int r = lane & 31, hh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -324,40 +324,72 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   constexpr int EHANDLED = ((KSTEPS - 1 + ESTRIDE - 1) / ESTRIDE) < NFR ? ((KSTEPS - 1 + ESTRIDE - 1) / ESTRIDE) : NFR;
   unsigned packed[DEFER ? MF : 1][DEFER ? NF : 1][8];
   bool pend = false;
-  int e_img = 0, e_tyi = 0, e_txi = 0, e_nbi = 0;
-  auto store_frag = [&](int m, int q) {   // fragment (m, q) of the item recorded in e_*
-    const int pm = DEFER ? m : 0, pq = DEFER ? q : 0;
-    const int cb0 = (e_nbi * (NT / 32) + wn * NF + q) * 32;
-    bf16_t* dst; int cd, co, dydx = 0;
-    if (d2s) { cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0; }
-    else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
-    else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
-    // transpose the 32 pixel x 32 channel fragment through a wave-private LDS scratch so that
-    // consecutive lanes store consecutive 16-B chunks (whole 64-B channel rows per pixel)
+  // Output addressing of the item being stored, all wave-uniform (SGPRs): the 64-bit base of the wave's first
+  // fragment row per channel fragment q, the byte step between fragment rows and between adjacent pixels.
+  // Set once per item by set_item(); a fragment then costs one 64-bit add instead of a full NHWC index.
+  int e_tyi = 0, e_txi = 0;
+  unsigned char* e_fb[NF];
+  unsigned e_rowb[NF], e_pstep[NF];
+#pragma unroll
+  for (int q = 0; q < NF; ++q) { e_fb[q] = nullptr; e_rowb[q] = 0; e_pstep[q] = 0; }
+  auto set_item = [&](int img, int tyi, int txi, int nbi) {
+    e_tyi = tyi; e_txi = txi;
+    const int oy0 = tyi * TH + wm * MF;
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      const int cb0 = (nbi * (NT / 32) + wn * NF + q) * 32;
+      bf16_t* dst; int cd, co, dydx = 0;
+      if (d2s) { cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0; }
+      else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
+      else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
+      const size_t pix0 = d2s ? ((size_t)img * (2 * p.h) + 2 * oy0 + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * (txi * TW) + (dydx & 1)
+                              : ((size_t)img * p.h + oy0) * p.w + txi * TW;
+      e_fb[q] = reinterpret_cast<unsigned char*>(dst + pix0 * cd + co);
+      e_rowb[q] = (d2s ? 8u : 2u) * (unsigned)p.w * (unsigned)cd;   // one output row down (two for the deconv scatter)
+      e_pstep[q] = (d2s ? 4u : 2u) * (unsigned)cd;                  // bytes between horizontally adjacent output pixels
+    }
+  };
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  // A fragment leaves in three moves: (1) bf16 pairs into the wave-private LDS scratch, pixel-major, so that
+  // (2) consecutive lanes read back consecutive 16-B chunks (whole 64-B channel rows per pixel) and (3) store them.
+  auto frag_to_lds = [&](const unsigned (&pk)[8]) {
     unsigned char* sc = oscr + wave * (32 * 80);
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const u32x2 v = {packed[pm][pq][2 * g], packed[pm][pq][2 * g + 1]};
+      const u32x2 v = {pk[2 * g], pk[2 * g + 1]};
       *reinterpret_cast<u32x2*>(sc + r * 80 + (8 * g + 4 * hh) * 2) = v;   // pixel r, channels 8g+4hh..+3
     }
-    const int oy = e_tyi * TH + wm * MF + m;
-    if (RAGGED && oy >= p.h) return;   // ragged last tile row (wave-uniform)
-    const int wlim = (RAGGED && (e_txi + 1) * TW > p.w) ? p.w - e_txi * TW : TW;
-    // address = wave-uniform 64-bit base of the fragment's first pixel (scalar ALU) + a 32-bit lane offset:
-    // the per-lane 64-bit multiplies this replaces cost more issue slots than the stores themselves
-    const size_t pix0 = d2s ? ((size_t)e_img * (2 * p.h) + 2 * oy + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * (e_txi * TW) + (dydx & 1)
-                            : ((size_t)e_img * p.h + oy) * p.w + e_txi * TW;
-    unsigned char* const fb = reinterpret_cast<unsigned char*>(dst + pix0 * cd + co);
-    const unsigned pstep = (d2s ? 4u : 2u) * (unsigned)cd;   // bytes between horizontally adjacent output pixels
+  };
+  auto frag_from_lds = [&](u32x4 (&tv)[2]) {
+    const unsigned char* sc = oscr + wave * (32 * 80);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int chunk = lane + 64 * k;   // 128 chunks of 16 B: pixel = chunk / 4, part = chunk % 4
-      const int px = chunk >> 2, part = chunk & 3;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(sc + px * 80 + part * 16);
-      if (RAGGED && px >= wlim) continue;   // ragged last tile column
-      *reinterpret_cast<u32x4*>(fb + (__umul24((unsigned)px, pstep) + (unsigned)part * 16u)) = v;
+      tv[k] = *reinterpret_cast<const u32x4*>(sc + (chunk >> 2) * 80 + (chunk & 3) * 16);
     }
+  };
+  auto frag_store = [&](int m, int q, const u32x4 (&tv)[2]) {
+    if (RAGGED && e_tyi * TH + wm * MF + m >= p.h) return;   // ragged last tile row (wave-uniform)
+    const int wlim = (RAGGED && (e_txi + 1) * TW > p.w) ? p.w - e_txi * TW : TW;
+    unsigned char* const fb = e_fb[q] + (size_t)m * e_rowb[q];
+    const unsigned pstep = e_pstep[q];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int chunk = lane + 64 * k;
+      const int px = chunk >> 2, part = chunk & 3;
+      if (RAGGED && px >= wlim) continue;   // ragged last tile column
+#ifndef ABL_NO_STORE
+      *reinterpret_cast<u32x4*>(fb + (__umul24((unsigned)px, pstep) + (unsigned)part * 16u)) = tv[k];
+#else   // diagnostic build: same instruction stream, the store never executes
+      if (tv[k][0] == 0x12345678u && tv[k][1] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(fb + (__umul24((unsigned)px, pstep) + (unsigned)part * 16u)) = tv[k];
+#endif
+    }
+  };
+  auto store_frag = [&](int m, int q) {   // fragment (m, q) of the item recorded by set_item, back to back
+    u32x4 tv[2];
+    frag_to_lds(packed[DEFER ? m : 0][DEFER ? q : 0]);
+    frag_from_lds(tv);
+    frag_store(m, q, tv);
   };
 
   __syncthreads();  // stage 0 is in LDS
@@ -382,6 +414,70 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     }
 
     const int tile = tile_c, nbi = nbi_c;
+    if constexpr (WRES) {
+      // ---- resident weights (Cin = 32, one channel fragment per wave): every stage is a whole item ----
+      // The MFMAs run fragment-major (all 18 steps of output row m, then row m+1: a single accumulation chain
+      // issues at the full matrix rate) and the epilogue of row m -- bf16 pack, LDS transpose, BatchNorm sums,
+      // stores: ~35 instructions with two LDS round trips -- is spread over the MFMA steps of row m+1, each
+      // wait ~4 steps behind its issue.  Only the last row's epilogue is exposed.  Done back to back after the
+      // phase, the four epilogues took 3.0 k cycles per stage next to 2.7 k cycles of MFMAs (timeline, round 1).
+      static_assert(!WRES || NF == 1, "resident-weight kernels hold one channel fragment per wave");
+      if (wave == 0) TRACE(0, sidx);
+      set_item(img_c, tyi_c, txi_c, nbi);
+      const bool rag = RAGGED && STATS && ((tyi_c + 1) * TH > p.h || (txi_c + 1) * TW > p.w);
+      const bool col_in = !RAGGED || (txi_c * TW + r) < p.w;   // lane = pixel column
+      const unsigned char* lb = buf0 + cur * BUFB + ((wm * MF) * LW + r) * PIXB + 8 * hh * 2;
+      auto xoff = [](int s, int m) constexpr {
+        const int tap = s >> 1, k16 = s & 1;
+        return ((m + tap / 3) * LW + tap % 3) * PIXB + k16 * 32;
+      };
+      unsigned pk[8];
+      u32x4 tv[2];
+      auto epi = [&](int mp, int s) __attribute__((always_inline)) {   // piece s (1..10) of the epilogue of output row mp
+        if (s == 1) {
+          if (RAGGED && STATS) {   // ragged last tile: pixels outside the image must not reach the BatchNorm sums
+            const bool in = !rag || (col_in && (tyi_c * TH + wm * MF + mp) < p.h);   // branch-free: a branch here
+#pragma unroll                                                                        // keeps hipcc from unrolling
+            for (int i = 0; i < 16; ++i) acc[mp][0][i] = in ? acc[mp][0][i] : 0.f;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            pk[2 * g] = pack_bf16x2(acc[mp][0][4 * g], acc[mp][0][4 * g + 1]);
+            pk[2 * g + 1] = pack_bf16x2(acc[mp][0][4 * g + 2], acc[mp][0][4 * g + 3]);
+          }
+          frag_to_lds(pk);
+        }
+        if (STATS && s >= 2 && s < 6) {
+#pragma unroll
+          for (int i = 4 * (s - 2); i < 4 * (s - 2) + 4; ++i) {
+            s1[0][i] += acc[mp][0][i];
+            s2[0][i] = fmaf(acc[mp][0][i], acc[mp][0][i], s2[0][i]);
+            asm volatile("" : "+v"(s1[0][i]), "+v"(s2[0][i]));   // pin the sums to this step: LLVM otherwise sinks
+          }                                                        // all of them behind the stage's barrier
+        }
+        if (s == 6) frag_from_lds(tv);
+        if (s == 10) frag_store(mp, 0, tv);
+      };
+      constexpr int LD = 2, KT = MF * KSTEPS;   // one ring of LD+1 activation fragments across all rows
+      Frag xr[LD + 1];
+#pragma unroll
+      for (int k = 0; k < LD; ++k) xr[k] = M::load(lb + xoff(k % KSTEPS, k / KSTEPS));
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {   // (nested: hipcc gives up on one 72-trip loop in the ragged instantiations)
+        const int k = m * KSTEPS + s;
+        if (k + LD < KT) xr[(k + LD) % (LD + 1)] = M::load(lb + xoff((k + LD) % KSTEPS, (k + LD) / KSTEPS));
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads of step k+LD ahead of the MFMA of step k
+        if (s == 0) M::mma0(acc[m][0], wres[0][0], xr[k % (LD + 1)]);
+        else M::mma(acc[m][0], wres[s][0], xr[k % (LD + 1)]);
+        if (m > 0) epi(m - 1, s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (wave == 0) TRACE(1, sidx);
+#pragma unroll
+      for (int s = 1; s <= 10; ++s) epi(MF - 1, s);
+    } else {
     if (ch == 0) {
 #pragma unroll
       for (int m = 0; m < MF; ++m)
@@ -479,19 +575,16 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
             for (int i = 0; i < 16; ++i) acc[m][q][i] = in ? acc[m][q][i] : 0.f;
         }
       }
+      if (!DEFER) set_item(img, tyi, txi, nbi);
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
-        const int cb0 = (nbi * (NT / 32) + wn * NF + q) * 32;
-        bf16_t* dst; int cd, co, dydx = 0;
-        if (d2s) {
-          cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0;
-        } else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
-        else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
         // deconv bias from LDS (staged at kernel start): a global load here would put a vmcnt(0) --
         // i.e. a drain of the weight ring and of all earlier output stores -- into every epilogue
         const bool has_bias = d2s && p.bias != nullptr;   // compile-time false in the 3x3 kernels
         float bv[16];
         if (has_bias) {
+          const int cb0 = (nbi * (NT / 32) + wn * NF + q) * 32;
+          const int co = cb0 % (p.cout >> 2);   // channel inside the (dy, dx) quarter
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + co + 8 * g + 4 * hh);
@@ -514,7 +607,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
               packed[DEFER ? m : 0][DEFER ? q : 0][2 * g + 1] = pack_bf16x2(acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]);
             }
           }
-          if (!DEFER) { e_img = img; e_tyi = tyi; e_txi = txi; e_nbi = nbi; store_frag(m, q); }
+          if (!DEFER) store_frag(m, q);
           if (STATS) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -524,7 +617,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           }
         }
       }
-      if (DEFER) { e_img = img; e_tyi = tyi; e_txi = txi; e_nbi = nbi; pend = true; }
+      if (DEFER) { set_item(img, tyi, txi, nbi); pend = true; }
       if (STATS && !WRES) {
         float* ws = wg_stats + parity * (WM * 2 * NT);
 #pragma unroll
@@ -544,6 +637,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       }
     }
 
+    }
     if (wave == 0) TRACE(2, sidx);
     __syncthreads();
     if (wave == 0) TRACE(3, sidx);
