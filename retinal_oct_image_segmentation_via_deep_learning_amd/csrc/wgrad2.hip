@@ -256,20 +256,54 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
       return ((psx * ROWS + (k >> 1) + ty) * LW + (k & 1) * 16 + tx) * 64;
     };
-    constexpr int NSEQ = NK * TAPS;
-    bf16x8 bq[3];
-    bf16x8 aq[2];
-    aq[0] = tr_frag(dy_t + a_off(0));
-    bq[0] = tr_frag(in_t + b_off(0, 0));
-    if (NSEQ > 1) bq[1] = tr_frag(in_t + b_off(1 / TAPS, 1 % TAPS));
+    if constexpr (TAPS == 9) {
+      // Walk the INPUT rows of the wave's strip: the fragment of (input row i, half, tx) is read once and
+      // multiplied with the dY fragments of output rows i, i-1, i-2 (taps ty = 0, 1, 2), which sit in a
+      // four-slot register window.  0.44 transposed reads per MFMA instead of 1.11: with one read per MFMA
+      // the four waves asked the LDS for 142 B/clk, more than the 128 B/clk it delivers.
+      constexpr int NI = ROWS + 2, NB = NI * 6;
+      auto bo = [&](int j) { return ((psx * ROWS + j / 6) * LW + ((j / 3) & 1) * 16 + j % 3) * 64; };
+      bf16x8 aw[4][2];
+      bf16x8 bq[3];
+      aw[0][0] = tr_frag(dy_t + a_off(0));
+      aw[0][1] = tr_frag(dy_t + a_off(1));
+      bq[0] = tr_frag(in_t + bo(0));
+      bq[1] = tr_frag(in_t + bo(1));
 #pragma unroll
-    for (int i = 0; i < NSEQ; ++i) {
-      const int k = i / TAPS, t = i % TAPS;
-      if (i + 2 < NSEQ) bq[(i + 2) % 3] = tr_frag(in_t + b_off((i + 2) / TAPS, (i + 2) % TAPS));
-      if (t == 0 && k + 1 < NK) aq[(k + 1) & 1] = tr_frag(dy_t + a_off(k + 1));
-      __builtin_amdgcn_sched_barrier(0);
-      if (do_bias && t == 0) M::mma(accb, aq[k & 1], ones);
-      M::mma(acc[t], aq[k & 1], bq[i % 3]);
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int hx = 0; hx < 6; ++hx) {
+          const int j = i * 6 + hx, h = hx / 3, tx = hx % 3;
+          if (j + 2 < NB) bq[(j + 2) % 3] = tr_frag(in_t + bo(j + 2));
+          if (hx == 0 && i + 1 < ROWS) {   // dY of the next output row, a whole input row ahead of its first use
+            aw[(i + 1) & 3][0] = tr_frag(dy_t + a_off(2 * (i + 1)));
+            aw[(i + 1) & 3][1] = tr_frag(dy_t + a_off(2 * (i + 1) + 1));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ty = 0; ty < 3; ++ty) {
+            const int k = i - ty;   // output row that sees input row i through tap row ty
+            if (k < 0 || k >= ROWS) continue;
+            if (do_bias && ty == 0 && tx == 0) M::mma(accb, aw[k & 3][h], ones);
+            M::mma(acc[ty * 3 + tx], aw[k & 3][h], bq[j % 3]);
+          }
+        }
+    } else {
+      constexpr int NSEQ = NK * TAPS;
+      bf16x8 bq[3];
+      bf16x8 aq[2];
+      aq[0] = tr_frag(dy_t + a_off(0));
+      bq[0] = tr_frag(in_t + b_off(0, 0));
+      if (NSEQ > 1) bq[1] = tr_frag(in_t + b_off(1 / TAPS, 1 % TAPS));
+#pragma unroll
+      for (int i = 0; i < NSEQ; ++i) {
+        const int k = i / TAPS, t = i % TAPS;
+        if (i + 2 < NSEQ) bq[(i + 2) % 3] = tr_frag(in_t + b_off((i + 2) / TAPS, (i + 2) % TAPS));
+        if (t == 0 && k + 1 < NK) aq[(k + 1) & 1] = tr_frag(dy_t + a_off(k + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_bias && t == 0) M::mma(accb, aq[k & 1], ones);
+        M::mma(acc[t], aq[k & 1], bq[i % 3]);
+      }
     }
     __syncthreads();
     cur ^= 1;
