@@ -354,6 +354,53 @@ __global__ void dact_pool_coalesced_kernel(const T* da, const T* __restrict__ dp
   block_reduce_store<V>(s1, s2, g, G, c, partials, true, nullptr);
 }
 
+// Un-pooled layers with 8-channel groups that divide the workgroup: the NHWC tensor is a flat array of
+// 16-B groups, thread t always owns channel group t % G (the grid stride is a multiple of G), so there is
+// no index arithmetic at all, the BatchNorm coefficients are loaded ONCE, and U groups per tensor are in
+// flight per thread.  The general kernel above re-derives (image, row, column, group) with 64-bit divisions
+// and re-loads eight coefficient vectors per 32 B of payload: it ran at 3.0 TB/s (reduce-only) where this
+// shape of access reaches the copy rate.
+template <typename T, int U>
+__global__ void __launch_bounds__(EW_THREADS) dact_bn_reduce_flat_kernel(
+    const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, T* g_out,
+    float* __restrict__ partials, size_t total, int c) {
+  constexpr int V = 8;
+  const int G = c / V, gi = threadIdx.x % G;
+  float sc[V], sh[V], mu[V], is[V], s1[V], s2[V];
+  ldv<float, V>(scale + gi * V, sc); ldv<float, V>(shift + gi * V, sh);
+  ldv<float, V>(mean + gi * V, mu); ldv<float, V>(invstd + gi * V, is);
+#pragma unroll
+  for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const size_t stride = (size_t)gridDim.x * EW_THREADS;
+  size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  auto one = [&](const float (&yv)[V], const float (&dv)[V], size_t at) {
+    float gv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float z = fmaf(yv[j], sc[j], sh[j]);
+      gv[j] = z > 0.f ? dv[j] : 0.f;
+      const float gr = to_f32(from_f32<T>(gv[j]));   // statistics of the value as stored
+      s1[j] += gr;
+      s2[j] += gr * ((yv[j] - mu[j]) * is[j]);
+    }
+    if (g_out) store_vec<T, V>(g_out + at * V, gv);   // reduce-only mode: bn_bwd_apply re-derives the mask
+  };
+  for (; i + (U - 1) * stride < total; i += U * stride) {
+    float yv[U][V], dv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { ldv<T, V>(y + (i + u * stride) * V, yv[u]); ldv<T, V>(da + (i + u * stride) * V, dv[u]); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(yv[u], dv[u], i + u * stride);
+  }
+  for (; i < total; i += stride) {
+    float yv[V], dv[V];
+    ldv<T, V>(y + i * V, yv); ldv<T, V>(da + i * V, dv);
+    one(yv, dv, i);
+  }
+  block_reduce_store<V>(s1, s2, gi, G, c, partials, true, nullptr);
+}
+
 extern "C" int oct_dact_bn_reduce_blocks(int n, int h, int w, int c, int has_pool) {
   const int v = vec_width(c);
   if (has_pool && v == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0)  // coalesced pooled kernel: item = (row pair, x)
@@ -385,6 +432,18 @@ extern "C" int oct_dact_bn_reduce(int dtype, const void* da, const void* dpool, 
     else
       OCT_CHECK(false, "oct_dact_bn_reduce: bad dtype");
     return oct_check_launch("dact_pool_coalesced");
+  }
+  if (!dpool && v == 8 && reg) {
+    const size_t total = (size_t)n * h * w * (c / 8);
+    if (dtype == OCT_DT_BF16)
+      hipLaunchKernelGGL((dact_bn_reduce_flat_kernel<bf16_t, 4>), dim3(blocks), dim3(EW_THREADS), 0, s, (const bf16_t*)da,
+                         (const bf16_t*)y, scale, shift, mean, invstd, (bf16_t*)g, partials, total, c);
+    else if (dtype == OCT_DT_F32)
+      hipLaunchKernelGGL((dact_bn_reduce_flat_kernel<float, 2>), dim3(blocks), dim3(EW_THREADS), 0, s, (const float*)da,
+                         (const float*)y, scale, shift, mean, invstd, (float*)g, partials, total, c);
+    else
+      OCT_CHECK(false, "oct_dact_bn_reduce: bad dtype");
+    return oct_check_launch("dact_bn_reduce_flat");
   }
 #define LAUNCH(T, V, P) hipLaunchKernelGGL((dact_bn_reduce_kernel<T, V, P>), dim3(blocks), dim3(EW_THREADS), lds, s, \
                                            (const T*)da, (const T*)dpool, (const T*)y, scale, shift, mean, invstd, \
@@ -467,6 +526,42 @@ __global__ void bn_bwd_apply_kernel(T* g, const T* __restrict__ y, const float* 
     store_vec<T, V>(g + pix * c + gi * V, gv);
   }
 }
+// flat variant (see dact_bn_reduce_flat_kernel): coefficients once per thread, no index arithmetic
+template <typename T, int U>
+__global__ void __launch_bounds__(EW_THREADS) bn_bwd_apply_flat_kernel(T* g, const T* __restrict__ y,
+                                                                      const float* __restrict__ coef,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, size_t total, int c) {
+  constexpr int V = 8;
+  const int G = c / V, gi = threadIdx.x % G;
+  float k0[V], k1[V], k2[V], sc[V], sh[V];
+  ldv<float, V>(coef + gi * V, k0); ldv<float, V>(coef + c + gi * V, k1); ldv<float, V>(coef + 2 * c + gi * V, k2);
+  const bool masked = scale != nullptr;
+  if (masked) { ldv<float, V>(scale + gi * V, sc); ldv<float, V>(shift + gi * V, sh); }
+  const size_t stride = (size_t)gridDim.x * EW_THREADS;
+  size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  auto one = [&](float (&gv)[V], const float (&yv)[V], size_t at) {
+    if (masked) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) gv[j] = fmaf(yv[j], sc[j], sh[j]) > 0.f ? gv[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) gv[j] = fmaf(k0[j], gv[j], fmaf(k1[j], yv[j], k2[j]));
+    store_vec<T, V>(g + at * V, gv);
+  };
+  for (; i + (U - 1) * stride < total; i += U * stride) {
+    float gv[U][V], yv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { ldv<T, V>(g + (i + u * stride) * V, gv[u]); ldv<T, V>(y + (i + u * stride) * V, yv[u]); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(gv[u], yv[u], i + u * stride);
+  }
+  for (; i < total; i += stride) {
+    float gv[V], yv[V];
+    ldv<T, V>(g + i * V, gv); ldv<T, V>(y + i * V, yv);
+    one(gv, yv, i);
+  }
+}
 extern "C" int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const float* scale,
                                 const float* shift, size_t npix, int c, void* stream) {
   OCT_CHECK(g && y && coef && npix > 0 && c > 0, "oct_bn_bwd_apply: bad args");
@@ -474,6 +569,18 @@ extern "C" int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* 
   const int v = vec_width(c);
   const int blocks = ew_blocks(npix, c / v);
   hipStream_t s = as_stream(stream);
+  if (v == 8 && lane_mapping_ok(c, 8)) {
+    const size_t total = npix * (size_t)(c / 8);
+    if (dtype == OCT_DT_BF16)
+      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<bf16_t, 4>), dim3(blocks), dim3(EW_THREADS), 0, s, (bf16_t*)g,
+                         (const bf16_t*)y, coef, scale, shift, total, c);
+    else if (dtype == OCT_DT_F32)
+      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<float, 2>), dim3(blocks), dim3(EW_THREADS), 0, s, (float*)g,
+                         (const float*)y, coef, scale, shift, total, c);
+    else
+      OCT_CHECK(false, "oct_bn_bwd_apply: bad dtype");
+    return oct_check_launch("bn_bwd_apply_flat");
+  }
 #define LAUNCH(T, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(blocks), dim3(EW_THREADS), 0, s, (T*)g, \
                                         (const T*)y, coef, scale, shift, npix, c)
   if (dtype == OCT_DT_BF16) { if (v == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 1); }
