@@ -321,9 +321,9 @@ __global__ void dact_pool_coalesced_kernel(const T* da, const T* __restrict__ dp
     const bool odd = (x & 1) != 0;
     const size_t p0 = ((size_t)img * h + 2 * yi) * w + x, p1 = p0 + w;
     float y0[V], y1[V], d0[V], d1[V], dp[V];
-    load_vec<T, V>(y + p0 * c + g * V, y0);
-    load_vec<T, V>(y + p1 * c + g * V, y1);
-    if (da) { load_vec<T, V>(da + p0 * c + g * V, d0); load_vec<T, V>(da + p1 * c + g * V, d1); }
+    load_vec_nt<T, V>(y + p0 * c + g * V, y0);
+    load_vec_nt<T, V>(y + p1 * c + g * V, y1);
+    if (da) { load_vec_nt<T, V>(da + p0 * c + g * V, d0); load_vec_nt<T, V>(da + p1 * c + g * V, d1); }
     load_vec<T, V>(dpool + (((size_t)img * ho + yi) * wo + (x >> 1)) * c + g * V, dp);
     float g0[V], g1[V];
 #pragma unroll
@@ -348,8 +348,8 @@ __global__ void dact_pool_coalesced_kernel(const T* da, const T* __restrict__ dp
       s2[j] = fmaf(r0, (y0[j] - mu[j]) * is[j], s2[j]);
       s2[j] = fmaf(r1, (y1[j] - mu[j]) * is[j], s2[j]);
     }
-    store_vec<T, V>(g_out + p0 * c + g * V, g0);
-    store_vec<T, V>(g_out + p1 * c + g * V, g1);
+    store_vec_nt<T, V>(g_out + p0 * c + g * V, g0);
+    store_vec_nt<T, V>(g_out + p1 * c + g * V, g1);
   }
   block_reduce_store<V>(s1, s2, g, G, c, partials, true, nullptr);
 }
@@ -384,12 +384,12 @@ __global__ void __launch_bounds__(EW_THREADS) dact_bn_reduce_flat_kernel(
       s1[j] += gr;
       s2[j] += gr * ((yv[j] - mu[j]) * is[j]);
     }
-    if (g_out) store_vec<T, V>(g_out + at * V, gv);   // reduce-only mode: bn_bwd_apply re-derives the mask
+    if (g_out) store_vec_nt<T, V>(g_out + at * V, gv);   // reduce-only mode: bn_bwd_apply re-derives the mask
   };
   for (; i + (U - 1) * stride < total; i += U * stride) {
     float yv[U][V], dv[U][V];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { ldv<T, V>(y + (i + u * stride) * V, yv[u]); ldv<T, V>(da + (i + u * stride) * V, dv[u]); }
+    for (int u = 0; u < U; ++u) { load_vec_nt<T, V>(y + (i + u * stride) * V, yv[u]); load_vec_nt<T, V>(da + (i + u * stride) * V, dv[u]); }
 #pragma unroll
     for (int u = 0; u < U; ++u) one(yv[u], dv[u], i + u * stride);
   }
@@ -547,12 +547,12 @@ __global__ void __launch_bounds__(EW_THREADS) bn_bwd_apply_flat_kernel(T* g, con
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) gv[j] = fmaf(k0[j], gv[j], fmaf(k1[j], yv[j], k2[j]));
-    store_vec<T, V>(g + at * V, gv);
+    store_vec_nt<T, V>(g + at * V, gv);
   };
   for (; i + (U - 1) * stride < total; i += U * stride) {
     float gv[U][V], yv[U][V];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { ldv<T, V>(g + (i + u * stride) * V, gv[u]); ldv<T, V>(y + (i + u * stride) * V, yv[u]); }
+    for (int u = 0; u < U; ++u) { load_vec_nt<T, V>(g + (i + u * stride) * V, gv[u]); load_vec_nt<T, V>(y + (i + u * stride) * V, yv[u]); }
 #pragma unroll
     for (int u = 0; u < U; ++u) one(gv[u], yv[u], i + u * stride);
   }

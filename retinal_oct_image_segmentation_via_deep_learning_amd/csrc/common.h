@@ -56,6 +56,32 @@ __device__ __forceinline__ void store_vec(T* p, const float (&in)[V]) {
   *reinterpret_cast<VecT<T, V>*>(p) = t;
 }
 
+// streaming variants: the data is not re-read by this kernel (nontemporal = "nt" cache policy)
+template <typename T, int V>
+__device__ __forceinline__ void load_vec_nt(const T* p, float (&out)[V]) {
+  typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+  constexpr int NQ = (sizeof(T) * V) / 16;
+  static_assert(NQ >= 1 && (sizeof(T) * V) % 16 == 0, "16-B multiples only");
+  VecT<T, V> t;
+  nt_u4* q = reinterpret_cast<nt_u4*>(&t);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) q[i] = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p) + i);
+#pragma unroll
+  for (int i = 0; i < V; ++i) out[i] = to_f32(t.v[i]);
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_vec_nt(T* p, const float (&in)[V]) {
+  typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+  constexpr int NQ = (sizeof(T) * V) / 16;
+  static_assert(NQ >= 1 && (sizeof(T) * V) % 16 == 0, "16-B multiples only");
+  VecT<T, V> t;
+#pragma unroll
+  for (int i = 0; i < V; ++i) t.v[i] = from_f32<T>(in[i]);
+  const nt_u4* q = reinterpret_cast<const nt_u4*>(&t);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) __builtin_nontemporal_store(q[i], reinterpret_cast<nt_u4*>(p) + i);
+}
+
 // MFMA wrappers: one "k16 step" = 16 contraction elements, 8 per lane (lane>>5 picks the half).
 // D[row][col] += sum_k A[row][k] * B[k][col]; lane l holds A[row=l&31][8*(l>>5)+j] and
 // B[8*(l>>5)+j][col=l&31], j=0..7; D: col = l&31, row = (i&3) + 8*(i>>2) + 4*(l>>5), i = reg.
