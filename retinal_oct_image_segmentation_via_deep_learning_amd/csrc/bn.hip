@@ -5,7 +5,12 @@
 #include "common.h"
 
 #define EW_THREADS 256
-#define EW_MAX_BLOCKS 2048
+// Grid cap of the streaming kernels: two workgroups per CU.  Measured on bn_bwd_apply (6 B/element over 1-GB
+// tensors): 256 / 512 / 1024 / 2048 / 4096 workgroups of one 16-B group per thread and iteration ->
+// 5.1 / 3.5 / 3.6 / 4.1 / 4.1 ms per step; more groups in flight per thread shift the optimum to fewer
+// workgroups (4 per thread: 3.5 ms at 256, 4.5 at 2048).  About 4 MB in flight chip-wide is the sweet spot;
+// beyond it the extra streams cost DRAM page locality.
+#define EW_MAX_BLOCKS 512
 
 // ---------------------------------------------------------------------------------------------
 // bn_finalize: partials [nblocks][2][c] -> statistics and fused affine coefficients
@@ -83,10 +88,10 @@ extern "C" int oct_bn_eval_coeffs(int c, const float* gamma, const float* beta, 
 // ---------------------------------------------------------------------------------------------
 static inline int vec_width(int c) { return (c % 8 == 0) ? 8 : 1; }
 static inline bool lane_mapping_ok(int c, int v) { return EW_THREADS % (c / v) == 0; }
-static inline int ew_blocks(size_t items, int groups) {
+static inline int ew_blocks(size_t items, int groups, size_t cap = EW_MAX_BLOCKS) {
   const size_t work = items * (size_t)groups;
   size_t b = (work + EW_THREADS - 1) / EW_THREADS;
-  if (b > EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -404,7 +409,7 @@ __global__ void __launch_bounds__(EW_THREADS) dact_bn_reduce_flat_kernel(
 extern "C" int oct_dact_bn_reduce_blocks(int n, int h, int w, int c, int has_pool) {
   const int v = vec_width(c);
   if (has_pool && v == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0)  // coalesced pooled kernel: item = (row pair, x)
-    return ew_blocks((size_t)n * (h / 2) * w, c / v);
+    return ew_blocks((size_t)n * (h / 2) * w, c / v, 2048);   // this kernel (five streams, shuffles) measured best at 2048: 1.11 vs 1.35 ms at 512
   const size_t items = has_pool ? (size_t)n * (h / 2) * (w / 2) : (size_t)n * h * w;
   return ew_blocks(items, c / v);
 }
@@ -572,10 +577,10 @@ extern "C" int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* 
   if (v == 8 && lane_mapping_ok(c, 8)) {
     const size_t total = npix * (size_t)(c / 8);
     if (dtype == OCT_DT_BF16)
-      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<bf16_t, 4>), dim3(blocks), dim3(EW_THREADS), 0, s, (bf16_t*)g,
+      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<bf16_t, 1>), dim3(blocks), dim3(EW_THREADS), 0, s, (bf16_t*)g,
                          (const bf16_t*)y, coef, scale, shift, total, c);
     else if (dtype == OCT_DT_F32)
-      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<float, 2>), dim3(blocks), dim3(EW_THREADS), 0, s, (float*)g,
+      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<float, 1>), dim3(blocks), dim3(EW_THREADS), 0, s, (float*)g,
                          (const float*)y, coef, scale, shift, total, c);
     else
       OCT_CHECK(false, "oct_bn_bwd_apply: bad dtype");
