@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   const int it1 = min(it0 + p.per_wg, p.nitems);
   if (it0 >= it1) return;
   const int nstage = (it1 - it0) * p.nch;
-  const int nstage_pad = (nstage + 3) / 4 * 4;   // producer ring depth D = 4
+  const int nstage_pad = (nstage + 3) / 4 * 4;   // a multiple of the producer ring depth (D = 2; 4 keeps the unrolled bodies' parity)
 
   // BN scale/shift of every input channel live in LDS: reading them with ds_read keeps them off the
   // vmcnt queue (a global load issued at commit time would be YOUNGER than the prefetched stages and
