@@ -25,6 +25,7 @@ struct Igemm2Params {
   bf16_t* y0; bf16_t* y1; float* stats; const float* bias;
   int n, h, w, c0, c1, cout, split, xf0, xf1, in_mode, out_mode;
   int tiles_x, tiles_y, nblk, nitems, per_wg, nch, nk16;
+  int interleave;   // 1: workgroup b walks tiles b, b + grid, b + 2*grid, ... (all channel blocks of a tile), 0: a contiguous item range
   unsigned long long* trace;  // diagnostic builds only (-DOCT_TRACE): s_memtime stamps of workgroup 0
 };
 
@@ -78,10 +79,24 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // the 3x3 kernels only run plain -> plain (plan_v2); the deconv modes belong to the 1x1 instantiations
   const bool s2d = TAPS == 1 && p.in_mode == OCT_IN_S2D;
   const bool d2s = TAPS == 1 && p.out_mode == OCT_OUT_D2S;
-  const int it0 = blockIdx.x * p.per_wg;
-  const int it1 = min(it0 + p.per_wg, p.nitems);
-  if (it0 >= it1) return;
-  const int nstage = (it1 - it0) * p.nch;
+  // Work of this workgroup: `nitems_wg` items (tile, channel block) starting at (tile t_first, block nbi_first),
+  // the tile index advancing by `tstep` whenever the channel blocks of a tile are done.  Large layers interleave
+  // the workgroups over the tiles (tstep = grid): at any time the chip works on ~256 consecutive tiles, i.e. on
+  // whole image rows -- DRAM pages are swept linearly and the halo rows shared by vertically adjacent tiles are
+  // fetched by workgroups running at the same time (Infinity Cache hits instead of a second HBM read).
+  int t_first, nbi_first, nitems_wg, tstep;
+  if (p.interleave) {
+    if ((int)blockIdx.x >= p.nitems / p.nblk) return;
+    t_first = blockIdx.x; nbi_first = 0; tstep = gridDim.x;
+    nitems_wg = ((p.nitems / p.nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * p.nblk;
+  } else {
+    const int it0 = blockIdx.x * p.per_wg;
+    const int it1 = min(it0 + p.per_wg, p.nitems);
+    if (it0 >= it1) return;
+    t_first = it0 / p.nblk; nbi_first = it0 - t_first * p.nblk; tstep = 1; nitems_wg = it1 - it0;
+  }
+  const int sx = tstep % p.tiles_x, sy = (tstep / p.tiles_x) % p.tiles_y, simg = tstep / (p.tiles_x * p.tiles_y);
+  const int nstage = nitems_wg * p.nch;
   const int nstage_pad = (nstage + 3) / 4 * 4;   // a multiple of the producer ring depth (D = 2; 4 keeps the unrolled bodies' parity)
 
   // BN scale/shift of every input channel live in LDS: reading them with ds_read keeps them off the
@@ -142,8 +157,8 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     const int last = nstage - 1;
     int i_sidx = 0, i_ch = 0, i_nbi, i_txi, i_tyi, i_img, c_sidx = 0, c_ch = 0;
     {
-      int t = it0 / p.nblk;
-      i_nbi = it0 - t * p.nblk;
+      int t = t_first;
+      i_nbi = nbi_first;
       i_txi = t % p.tiles_x; t /= p.tiles_x;
       i_tyi = t % p.tiles_y; i_img = t / p.tiles_y;
     }
@@ -155,7 +170,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           i_ch = 0;
           if (++i_nbi == p.nblk) {
             i_nbi = 0;
-            if (++i_txi == p.tiles_x) { i_txi = 0; if (++i_tyi == p.tiles_y) { i_tyi = 0; ++i_img; } }
+            i_txi += sx; if (i_txi >= p.tiles_x) { i_txi -= p.tiles_x; ++i_tyi; }
+            i_tyi += sy; if (i_tyi >= p.tiles_y) { i_tyi -= p.tiles_y; ++i_img; }
+            i_img += simg;
           }
         }
       }
@@ -394,8 +411,8 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 
   __syncthreads();  // stage 0 is in LDS
   int cur = 0, pending_tile = -1, pending_nbi = 0, parity = 0;
-  int item = it0, ch = 0;
-  int tile_c = it0 / p.nblk, nbi_c = it0 - tile_c * p.nblk;   // (tile, channel block) of `item`, kept as counters:
+  int item = 0, ch = 0;                                        // item = index within this workgroup's items
+  int tile_c = t_first, nbi_c = nbi_first;                     // (tile, channel block) of `item`, kept as counters:
                                                              // two integer divisions per stage cost ~200 cycles
   int txi_c = tile_c % p.tiles_x, tyi_c = (tile_c / p.tiles_x) % p.tiles_y, img_c = tile_c / (p.tiles_x * p.tiles_y);
   for (int sidx = 0; sidx < nstage_pad; ++sidx) {
@@ -500,7 +517,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         wbase = p.wp + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512 + lane * 8;
         int n_ch = ch + 1, n_item = item;
         if (n_ch == p.nch) { n_ch = 0; n_item = item + 1; }
-        if (n_item >= it1) { n_item = item; n_ch = ch; }  // last stage: harmless re-read of valid memory
+        if (n_item >= nitems_wg) { n_item = item; n_ch = ch; }  // last stage: harmless re-read of valid memory
         const int n_nbi = n_item == item ? nbi : (nbi + 1 == p.nblk ? 0 : nbi + 1);
         wbase_n = p.wp + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512 + lane * 8;
         if (sidx == 0) {
@@ -648,8 +665,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     if (++ch == p.nch) {
       ch = 0; ++item;
       if (++nbi_c == p.nblk) {
-        nbi_c = 0; ++tile_c;
-        if (++txi_c == p.tiles_x) { txi_c = 0; if (++tyi_c == p.tiles_y) { tyi_c = 0; ++img_c; } }
+        nbi_c = 0; tile_c += tstep;
+        txi_c += sx; if (txi_c >= p.tiles_x) { txi_c -= p.tiles_x; ++tyi_c; }
+        tyi_c += sy; if (tyi_c >= p.tiles_y) { tyi_c -= p.tiles_y; ++img_c; }
+        img_c += simg;
       }
     }
   }
@@ -702,7 +721,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct V2Plan { bool ok; int nt; int th; bool wres; int grid; int per_wg; int nitems; int nblk; int stat_rows; };
+struct V2Plan { bool ok; int nt; int th; bool wres; int grid; int per_wg; int nitems; int nblk; int stat_rows; int interleave; };
 
 static bool v2_enabled() {
   static int on = -1;
@@ -738,6 +757,11 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   if (target > pl.nitems) target = pl.nitems;
   pl.per_wg = (pl.nitems + target - 1) / target;
   pl.grid = (pl.nitems + pl.per_wg - 1) / pl.per_wg;
+  pl.interleave = 0;
+  if (ntiles >= 2 * target) {   // interleaved tile walk: one workgroup per CU, tiles b, b + 256, ...
+    pl.grid = target;
+    pl.interleave = 1;
+  }
   pl.stat_rows = pl.grid;   // one row [2][cout] per (persistent) workgroup
   return pl;
 }
@@ -784,6 +808,7 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.cout = d->cout; p.split = d->split;
   p.xf0 = d->xform0; p.xf1 = d->xform1;
   p.tiles_x = (d->w + 31) / 32; p.tiles_y = (d->h + pl.th - 1) / pl.th; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;
+  p.interleave = pl.interleave;
   const int ktot = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
   p.nch = ktot / 32; p.nk16 = ktot / 16;
   hipStream_t s = as_stream(stream);
