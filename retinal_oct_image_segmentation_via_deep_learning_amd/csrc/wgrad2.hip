@@ -22,6 +22,7 @@ struct Wgrad2Params {
   const bf16_t* dy; float* dwp; float* dbias;
   int n, h, w, c0, c1, ktot, cout, xf0, xf1, dy_mode;
   int tiles_x, tiles_y, ntiles, per_wg;
+  int interleave;   // 1: workgroup x walks tiles x, x + gridDim.x, ... (see igemm2.hip), 0: a contiguous tile range
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -60,9 +61,17 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_sb = blockIdx.y * (32 * CB), ci_sb = blockIdx.z * (32 * IB);
-  const int t0 = blockIdx.x * p.per_wg, t1 = min(t0 + p.per_wg, p.ntiles);
-  if (t0 >= t1) return;
-  const int nstage = t1 - t0;
+  int t0, tstep, nstage;
+  if (p.interleave) {
+    if ((int)blockIdx.x >= p.ntiles) return;
+    t0 = blockIdx.x; tstep = gridDim.x;
+    nstage = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  } else {
+    t0 = blockIdx.x * p.per_wg; tstep = 1;
+    const int t1 = min(t0 + p.per_wg, p.ntiles);
+    if (t0 >= t1) return;
+    nstage = t1 - t0;
+  }
   constexpr int DRING = ((CB * IB == 4 && TH == 8) || TH == 16) ? 2 : 4;   // stages of loads in flight per producer thread (register budget)
   const int nstage_pad = (nstage + DRING - 1) / DRING * DRING;
 
@@ -109,7 +118,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       dcode[j] = RAGGED ? ((ly >= p.h - (p.tiles_y - 1) * TH ? 2u : 0u) | (lx >= p.w - (p.tiles_x - 1) * TW ? 8u : 0u)) : 0u;
     }
     auto issue = [&](int s, Stage& S) {
-      int t = t0 + s;
+      int t = t0 + s * tstep;
       const int txi = t % p.tiles_x; t /= p.tiles_x;
       const int tyi = t % p.tiles_y; const int img = t / p.tiles_y;
       const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
@@ -352,7 +361,8 @@ static void launch_w2r(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx > p.ntiles) gx = p.ntiles;
   p.per_wg = (p.ntiles + gx - 1) / gx;
-  gx = (p.ntiles + p.per_wg - 1) / p.per_wg;
+  p.interleave = p.ntiles >= 2 * gx ? 1 : 0;
+  if (!p.interleave) gx = (p.ntiles + p.per_wg - 1) / p.per_wg;
   hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH, RAGGED>), dim3(gx, gy, gz), dim3(512), lds, s, p);
 }
 template <int TAPS, int CB, int IB, int TH>
