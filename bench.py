@@ -119,7 +119,7 @@ def main():
     # the one tools/traffic_report.py derived from two rocprofv3 --pmc passes over this same command
     # (profiles/*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of the conv kernels per step), when committed
     traffic = None
-    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v10_traffic.json")
+    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v11_traffic.json")
     if os.path.exists(tfile) and (args.batch, args.height, args.width, args.features) == (32, 512, 1024, 32):
         with open(tfile) as fh:
             conv = json.load(fh).get("conv", {})
