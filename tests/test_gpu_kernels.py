@@ -175,6 +175,58 @@ def test_conv3x3_wgrad(env, dt, shape):
     close(grad.cpu().numpy(), dw, dt, "wgrad", scale_tol=3e-5 if dt == "f32" else 4e-3)
 
 
+# Layers with >= 512 tiles interleave the persistent workgroups over the tiles (igemm2.hip / wgrad2.hip).
+# The numpy oracle is too slow at these sizes: the reference is torch's own fp32 convolution on the GPU
+# applied to the SAME bf16-rounded operands (a different implementation of the same contraction).
+INTERLEAVED_SHAPES = [
+    (16, 64, 256, 32, 0, 32),   # resident weights, 16-row tiles: 512 tiles
+    (4, 64, 512, 64, 0, 256),   # two channel blocks per tile, streamed weights: 512 tiles
+    (4, 62, 530, 32, 0, 64),    # ragged last tile row and column: 544 tiles
+    (4, 128, 512, 32, 32, 32),  # virtual concat at full-resolution proportions: 512 tiles
+]
+
+
+@pytest.mark.parametrize("shape", INTERLEAVED_SHAPES)
+def test_interleaved_tile_walk_matches_torch_convolution(env, shape):
+    L, E = env
+    dt = "bf16"
+    n, h, w, c0, c1, cout = shape
+    cin = c0 + c1
+    rng = np.random.default_rng(hash(shape) % 2**32 + 7)
+    eng = E.UNetEngine(1, 2, 4, dt)
+    src, eff = make_src(E, rng, dt, n, h, w, c0, c1, True)
+    xe = torch.from_numpy(eff).cuda()                                   # what the convolution sees (NCHW, fp32 values of bf16)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    wr = torch.from_numpy(rnd(wt, dt)).cuda()
+    # fprop + BatchNorm partial sums
+    wp = eng._pack("w", fdev(wt), L.PACK_CONV_FPROP, cout, cin)
+    y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    part = torch.full((eng._stat_blocks(cout, n, h, w, src), 2, cout), float("nan"), dtype=torch.float32, device="cuda")
+    eng._conv(src, wp, cout, 9, n, h, w, y, stats=part)
+    ref = torch.nn.functional.conv2d(xe, wr, padding=1).double()
+    close(host(y), ref.cpu().numpy(), dt, "interleaved fprop")
+    s = part.double().sum(0).cpu().numpy()
+    close(s[0], ref.sum(dim=(0, 2, 3)).cpu().numpy(), dt, "sum(y)", scale_tol=2e-3)
+    close(s[1], (ref ** 2).sum(dim=(0, 2, 3)).cpu().numpy(), dt, "sum(y^2)", scale_tol=2e-3)
+    # dgrad (split into the two sources of a virtual concat)
+    dy = rnd(rng.standard_normal((n, cout, h, w)), dt)
+    dyt = torch.from_numpy(dy).cuda()
+    wpd = eng._pack("wd", fdev(wt), L.PACK_CONV_DGRAD, cout, cin)
+    d0 = torch.full((n, h, w, c0), float("nan"), dtype=torch.bfloat16, device="cuda")
+    d1 = torch.full((n, h, w, c1), float("nan"), dtype=torch.bfloat16, device="cuda") if c1 else None
+    eng._conv(E.Src(dev(dy, dt), cout), wpd, cin, 9, n, h, w, d0, y1=d1, split=c0 if c1 else 0)
+    dx = torch.nn.grad.conv2d_input((n, cin, h, w), wr, dyt, padding=1).double().cpu().numpy()
+    close(host(d0), dx[:, :c0], dt, "interleaved dgrad part 0")
+    if c1:
+        close(host(d1), dx[:, c0:], dt, "interleaved dgrad part 1")
+    # wgrad
+    dwp = eng._wgrad(src, dev(dy, dt), cout, 9, n, h, w)
+    grad = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device="cuda")
+    eng._unpack(L.PACK_CONV_FPROP, dwp, grad, cout, cin, False)
+    dw = torch.nn.grad.conv2d_weight(xe, (cout, cin, 3, 3), dyt, padding=1).double().cpu().numpy()
+    close(grad.cpu().numpy(), dw, dt, "interleaved wgrad", scale_tol=4e-3)
+
+
 DECONV_SHAPES = [(2, 4, 8, 16, 8), (1, 8, 16, 64, 32), (1, 2, 2, 64, 32), (1, 4, 4, 8, 4), (1, 8, 32, 128, 64),
                  (2, 16, 32, 64, 32), (1, 8, 64, 256, 128), (1, 8, 32, 512, 256)]  # last three: pipelined bf16 path
 
