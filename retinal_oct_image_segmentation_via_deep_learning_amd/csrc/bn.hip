@@ -319,10 +319,13 @@ __global__ void dact_pool_coalesced_kernel(const T* da, const T* __restrict__ dp
   float sc[V], sh[V], mu[V], is[V];
   load_vec<float, V>(scale + g * V, sc); load_vec<float, V>(shift + g * V, sh);
   load_vec<float, V>(mean + g * V, mu); load_vec<float, V>(invstd + g * V, is);
-  for (size_t i = start; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    size_t r = i / G;
-    const int x = r % w; r /= w;
-    const int yi = r % ho; const int img = r / ho;
+  // 32-bit index arithmetic (the host routes tensors of 2^31 items and more to the general kernel): the five
+  // 64-bit divisions this loop head used to carry are ~500 instructions per 100 B of payload
+  const unsigned gshift = 31 - __builtin_clz((unsigned)G);   // G is a power of two
+  for (unsigned i = (unsigned)start; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+    unsigned r = i >> gshift;
+    const int x = r % (unsigned)w; r /= (unsigned)w;
+    const int yi = r % (unsigned)ho; const int img = r / (unsigned)ho;
     const bool odd = (x & 1) != 0;
     const size_t p0 = ((size_t)img * h + 2 * yi) * w + x, p1 = p0 + w;
     float y0[V], y1[V], d0[V], d1[V], dp[V];
@@ -408,7 +411,7 @@ __global__ void __launch_bounds__(EW_THREADS) dact_bn_reduce_flat_kernel(
 
 extern "C" int oct_dact_bn_reduce_blocks(int n, int h, int w, int c, int has_pool) {
   const int v = vec_width(c);
-  if (has_pool && v == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0)  // coalesced pooled kernel: item = (row pair, x)
+  if (has_pool && v == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0 && (size_t)n * (h / 2) * w * (c / 8) < (1u << 31))  // coalesced pooled kernel: item = (row pair, x)
     return ew_blocks((size_t)n * (h / 2) * w, c / v, 2048);   // this kernel (five streams, shuffles) measured best at 2048: 1.11 vs 1.35 ms at 512
   const size_t items = has_pool ? (size_t)n * (h / 2) * (w / 2) : (size_t)n * h * w;
   return ew_blocks(items, c / v);
@@ -427,7 +430,7 @@ extern "C" int oct_dact_bn_reduce(int dtype, const void* da, const void* dpool, 
   const int blocks = oct_dact_bn_reduce_blocks(n, h, w, c, dpool != nullptr);
   const size_t lds = (size_t)2 * c * sizeof(float);
   hipStream_t s = as_stream(stream);
-  if (dpool && v == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0) {
+  if (dpool && v == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0 && (size_t)n * (h / 2) * w * (c / 8) < (1u << 31)) {
     if (dtype == OCT_DT_BF16)
       hipLaunchKernelGGL(dact_pool_coalesced_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), 0, s, (const bf16_t*)da,
                          (const bf16_t*)dpool, (const bf16_t*)y, scale, shift, mean, invstd, (bf16_t*)g, partials, n, h, w, c);
