@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: B-scans/sec of one U-Net training step (forward + CE loss + backward +
-gradient all-reduce + SGD) -- BASELINE.json configs[1]: SOTAS/Layers_Segment UNet(1, 8),
+bucketed gradient all-reduce + SGD) -- BASELINE.json configs[1]: SOTAS/Layers_Segment UNet(1, 8),
 512x1024, bf16, batch 32 per MI355X, synthetic data, random-init weights.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one process per GPU.  Either the caller launches the ranks (torch.distributed.run: RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- when WORLD_SIZE is absent -- this
+script starts N rank processes itself BEFORE anything touches the GPU and relays rank 0's JSON line.
+A WORLD_SIZE that contradicts --gpus is an error (exit 2), never a relabelled single-GPU number.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live: every MFMA conv launch of one extra
 (untimed) step is bracketed with HIP events on the launch stream; `cpu_baseline` times the oracle's
 stock-torch port (oracle/torch_unet.py) on the host cores for a bounded sample (rank 0, N=1 only).
+
+  --backend gloo --dry-run   no kernels, CPU tensors: rendezvous, parameter/buffer broadcast, the
+                             bucketed reducer on the real flat-parameter layout, barrier, MAX-reduce and
+                             the JSON line (tests/test_ddp_cpu.py runs it with --gpus 2).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_BSCAN_TRAIN = 578.009e9   # 3*F_fwd - dgrad(enc1conv1), UNet(1,8) @ 512x1024
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
 def train_flops(features, classes, h, w, in_ch=1):
@@ -46,7 +59,19 @@ def train_flops(features, classes, h, w, in_ch=1):
     return 3.0 * fwd - first
 
 
-def main():
+def csrc_digest():
+    """sha256 over the kernel sources: profiles/*_traffic.json records it, so a traffic figure measured on
+    other kernels than the ones being timed is recognised as stale."""
+    d = os.path.join(ROOT, "retinal_oct_image_segmentation_via_deep_learning_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -57,31 +82,181 @@ def main():
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
+    ap.add_argument("--dry-run", action="store_true", help="no kernels: exercise the multi-rank plumbing on CPU tensors")
+    ap.add_argument("--bucket-mb", type=float, default=3.0, help="gradient bucket threshold (MB)")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+loss+backward as one HIP graph (no gain at batch 32: the queue never runs dry)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: the parent never imports torch.cuda / never touches the GPU
+# ---------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()          # exactly the children started above
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# dry run (CPU): everything of the N > 1 path except the kernels
+# ---------------------------------------------------------------------------------------------------
+def dry_run(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    from retinal_oct_image_segmentation_via_deep_learning_amd import UNet, ddp
+    from retinal_oct_image_segmentation_via_deep_learning_amd.optim import FlatParams
+
+    torch.manual_seed(100 + rank)       # different on purpose: the broadcast must make them rank 0's
+    model = UNet(1, args.classes, init_features=args.features)
+    layout = FlatParams(model.named_parameters())
+    ddp.broadcast_parameters(layout.flat_p)
+    ddp.broadcast_buffers(model)
+    buckets = ddp.bucket_plan_for(model, layout, int(args.bucket_mb * (1 << 20)))
+    red = ddp.GradAllReducer(layout.flat_g, world, buckets)
+    nstages = len(model._engine.backward_stages())
+    ddp.barrier()
+    t0 = time.perf_counter()
+    ok = True
+    for step in range(args.warmup + args.steps):
+        if step == args.warmup:
+            ddp.barrier()
+            t0 = time.perf_counter()
+        layout.flat_g.fill_(float(rank + 1 + step))
+        for idx in range(nstages):      # what UNetEngine.backward does with a stage hook
+            if idx in red.flush_stages:
+                red.stage_done(idx)
+        scale = red.finish()
+        expect = sum(r + 1 + step for r in range(world))
+        ok = ok and bool((layout.flat_g == expect).all()) and scale == 1.0 / world
+    ddp.barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    csum = torch.tensor([float(layout.flat_p.double().sum())], dtype=torch.float64)
+    same = True
+    if world > 1:
+        lo, hi = csum.clone(), csum.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = bool(lo.item() == hi.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "dry-run (no kernels)", "value": 0.0, "unit": "B-scans/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tt.item() / max(args.steps, 1) * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
+            "dry_run": True, "backend": dist.get_backend() if world > 1 else None,
+            "allreduce_ok": ok, "params_identical_after_broadcast": same,
+            "buckets": [[lo, hi] for _, lo, hi in red.buckets],
+            "bucket_launch_order": [k for k, _, _ in red.launch_log[:len(red.buckets)]],
+            "config": {"workload": "multi-rank plumbing of the UNet(1,%d,%d) step" % (args.classes, args.features),
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"}}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if (ok and same) else 1
+
+
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline(args):
+    """Reference path on the host cores: cfg1 always, the cfg2 shape at batch 1."""
+    from oracle import torch_unet
+    cores = torch_unet.physical_cores()
+    c1 = torch_unet.time_train_steps(4, 256, 256, classes=2, iters=8, threads=cores, model="bionet", budget_s=6.0)
+    c2 = torch_unet.time_train_steps(1, args.height, args.width, args.classes, args.features, iters=5,
+                                     threads=cores, budget_s=12.0)
+    return {
+        "value": round(c2["bscans_per_s_min"], 3), "unit": "B-scans/s", "cores": c2["threads"], "kind": "port",
+        "sample": f"oracle/torch_unet.py (stock torch fp32 port of the reference UNet), batch 1 x {args.height}x"
+                  f"{args.width}, fwd+loss+bwd+SGD, {c2['iters']} timed iterations after 1 warm-up, all "
+                  f"{cores} physical cores of this box's share: min {c2['s_per_iter_min']:.2f} s/iter, median "
+                  f"{c2['s_per_iter_median']:.2f} s/iter",
+        "median": round(c2["bscans_per_s_median"], 3),
+        "cfg1": {"value": round(c1["bscans_per_s_min"], 2), "median": round(c1["bscans_per_s_median"], 2),
+                 "unit": "B-scans/s", "cores": c1["threads"],
+                 "sample": f"BioNet_2020 UNet(1,2) port, batch 4 x 256x256 (BASELINE configs[0]), {c1['iters']} timed "
+                           f"iterations: min {c1['s_per_iter_min'] * 1e3:.0f} ms/iter, median "
+                           f"{c1['s_per_iter_median'] * 1e3:.0f} ms/iter"},
+    }
+
+
+def traffic_from_profile(args, launches):
+    """HBM bytes per conv launch.  PMC counters cannot be read from inside this process: the figure comes from
+    two separate rocprofv3 --pmc passes over this same command (tools/traffic.sh -> tools/traffic_report.py).
+    It is reported only when that file was produced from THESE kernel sources and this workload."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
+    if not os.path.exists(path):
+        return None, f"{TRAFFIC_FILE} missing"
+    with open(path) as fh:
+        doc = json.load(fh)
+    if (args.batch, args.height, args.width, args.features) != (32, 512, 1024, 32):
+        return None, "not the profiled workload"
+    if doc.get("csrc_digest") != csrc_digest():
+        print(f"bench.py: {TRAFFIC_FILE} was measured on other kernel sources (digest {doc.get('csrc_digest')} != "
+              f"{csrc_digest()}): roofline.traffic is withheld -- re-run tools/traffic.sh", file=sys.stderr)
+        return None, f"{TRAFFIC_FILE} is stale (kernel sources changed since it was measured)"
+    conv = doc.get("conv", {})
+    if not conv:
+        return None, f"{TRAFFIC_FILE} has no conv entry"
+    total = (conv["read_GB_per_step"] + conv["write_GB_per_step"]) * 1e9
+    return round(total / max(launches, 1)), f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, csrc {doc['csrc_digest']})"
+
+
+def worker(args) -> int:
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report a mislabelled number",
+              file=sys.stderr)
+        return 2
 
     import torch
     import torch.distributed as dist
     from retinal_oct_image_segmentation_via_deep_learning_amd import UNet, ddp
 
-    rank, world, local = ddp.init_from_env("nccl")
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    backend = "gloo" if args.dry_run and args.backend == "nccl" and not torch.cuda.is_available() else args.backend
+    rank, world, local = ddp.init_from_env(backend)
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     torch.manual_seed(0)
     model = UNet(1, args.classes, init_features=args.features, compute_dtype="bf16").to(dev).train()
     trainer = ddp.DataParallelTrainer(model, lr=0.01, momentum=0.9, use_graph=args.graph,
-                                      graph_warmup=max(1, min(2, args.warmup - 1)))
+                                      graph_warmup=max(1, min(2, args.warmup - 1)),
+                                      bucket_cap_bytes=int(args.bucket_mb * (1 << 20)))
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(args.batch, 1, args.height, args.width, generator=g).to(dev)
     t = torch.randint(0, args.classes, (args.batch, args.height, args.width), generator=g).to(dev)
 
     def sync():
         if world > 1:
-            dist.barrier()
+            ddp.barrier(local)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -115,19 +290,10 @@ def main():
         kinds[k][0] += 1
         kinds[k][1] += s.elapsed_time(e)
     achieved = flops_bscan * args.batch / (conv_ms * 1e-3) / 1e12
-    # HBM bytes per conv launch: PMC counters cannot be read from inside this process, so the figure is
-    # the one tools/traffic_report.py derived from two rocprofv3 --pmc passes over this same command
-    # (profiles/*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of the conv kernels per step), when committed
-    traffic = None
-    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v11_traffic.json")
-    if os.path.exists(tfile) and (args.batch, args.height, args.width, args.features) == (32, 512, 1024, 32):
-        with open(tfile) as fh:
-            conv = json.load(fh).get("conv", {})
-        if conv:
-            traffic = round((conv["read_GB_per_step"] + conv["write_GB_per_step"]) * 1e9 / max(len(prof), 1))
+    traffic, traffic_source = traffic_from_profile(args, len(prof))
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
         "kernel": "igemm_kernel + wgrad_kernel (conv stack, %d launches/step)" % len(prof),
         "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
         "flop_per_launch": flops_bscan * args.batch / max(len(prof), 1),
@@ -136,17 +302,9 @@ def main():
         "whole_step_frac": round(value / world * flops_bscan / 1e12 / PEAK_BF16_TFLOPS, 4),
     }
 
-    cpu_baseline = None
+    cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import torch_unet
-        cores = os.cpu_count() or 1
-        threads = min(cores, 16)
-        bs, best, th = torch_unet.time_train_steps(1, args.height, args.width, args.classes, args.features,
-                                                   iters=3, threads=threads)
-        cpu_baseline = {"value": round(bs, 3), "unit": "B-scans/s", "cores": th, "kind": "port",
-                        "sample": f"oracle/torch_unet.py (stock torch fp32 port of the reference UNet), batch 1 "
-                                  f"x {args.height}x{args.width}, fwd+loss+bwd+SGD, best of 3 after 1 warm-up "
-                                  f"({best:.2f} s/iter)"}
+        cpu = cpu_baseline(args)
 
     if rank == 0:
         out = {
@@ -158,14 +316,25 @@ def main():
                                    f"train step, {args.height}x{args.width}, batch {args.batch}/GPU "
                                    f"(BASELINE configs[1]{'/[2] data-parallel' if world > 1 else ''})",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "step": "fwd + CE loss + bwd + grad all-reduce + SGD(momentum)",
+                       "step": "fwd + CE loss + bwd + bucketed grad all-reduce + SGD(momentum); inputs resident in "
+                               "HBM (same batch every step, no H2D in the loop); wall-clock mean over the timed steps "
+                               "between barrier+synchronize",
+                       "grad_buckets_bytes": [4 * (hi - lo) for _, lo, hi in trainer.reducer.buckets],
                        "hip_graph": graph_used, "hip_graph_error": trainer.graph_error},
             "loss": float(loss[0].item()),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

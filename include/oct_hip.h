@@ -139,6 +139,9 @@ typedef struct OctWgradArgs {
   const void* dy_y; const float* dy_coef; const float* dy_scale; const float* dy_shift;
 } OctWgradArgs;
 int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
+/* 1 when oct_conv_wgrad accepts dy_coef (fused BatchNorm-backward apply) for this descriptor, else 0: the
+ * caller then materialises dY with oct_bn_bwd_apply first.  Host-only query, never fails.               */
+int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d);
 /* dwp -> torch-layout gradient.  mode: OCT_PACK_CONV_FPROP (grad[co][ci][tap]),
  * OCT_PACK_DECONV_FPROP (grad[ci][co][dydx]) or OCT_PACK_1X1_FPROP (grad[co][ci]).
  * accumulate != 0: grad += */

@@ -100,14 +100,38 @@ def loss_fn(probs, target, w_ce=1.0, w_dice=0.0, eps=1e-7):
     return w_ce * ce + w_dice * (1.0 - ((2 * inter + eps) / (ps + ys + eps)).mean())
 
 
-def time_train_steps(batch, height, width, classes=8, features=32, iters=3, threads=None):
-    """B-scans/s of fwd + loss + bwd + SGD on the host cores (fp32)."""
+def physical_cores():
+    """Physical cores this process may run on (SMT siblings counted once; the affinity mask is the box's share)."""
+    import os
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                seen.add(fh.read().strip())
+        except OSError:
+            seen.add(str(c))
+    return max(1, len(seen))
+
+
+def time_train_steps(batch, height, width, classes=8, features=32, iters=3, threads=None, model="unet",
+                     budget_s=None):
+    """fwd + loss + bwd + SGD on the host cores (fp32), 1 warm-up + up to `iters` timed iterations (stops
+    early once `budget_s` seconds of timed work are spent, never before 2 iterations).
+    model "unet": TorchUNet(1, classes, features) with nll_loss(log p); "bionet": TorchBioUNet(1, classes) with
+    cross_entropy on its logits (BASELINE cfg1).  Returns a dict (B-scans/s from the minimum and the median)."""
+    import statistics
     import time
     if threads:
         torch.set_num_threads(threads)
     torch.manual_seed(0)
-    model = TorchUNet(1, classes, features).train()
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    if model == "bionet":
+        net = TorchBioUNet(1, classes).train()
+        step_loss = lambda out, t: F.cross_entropy(out, t)   # noqa: E731
+    else:
+        net = TorchUNet(1, classes, features).train()
+        step_loss = loss_fn
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(batch, 1, height, width, generator=g)
     t = torch.randint(0, classes, (batch, height, width), generator=g)
@@ -115,9 +139,12 @@ def time_train_steps(batch, height, width, classes=8, features=32, iters=3, thre
     for i in range(iters + 1):
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        loss_fn(model(x), t).backward()
+        step_loss(net(x), t).backward()
         opt.step()
         if i:  # first iteration is warm-up
             times.append(time.perf_counter() - t0)
-    best = min(times)
-    return batch / best, best, torch.get_num_threads()
+            if budget_s is not None and len(times) >= 2 and sum(times) >= budget_s:
+                break
+    best, med = min(times), statistics.median(times)
+    return {"bscans_per_s_min": batch / best, "bscans_per_s_median": batch / med, "s_per_iter_min": best,
+            "s_per_iter_median": med, "iters": len(times), "threads": torch.get_num_threads()}

@@ -77,6 +77,7 @@ SIGNATURES = {
     "oct_pack_weights_batch": (c_int, [c_int, c_int, C.POINTER(PackJob), c_void_p]),
     "oct_conv_forward": (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvArgs), c_void_p]),
     "oct_conv_wgrad": (c_int, [C.POINTER(WgradDesc), C.POINTER(WgradArgs), c_void_p]),
+    "oct_conv_wgrad_fused_apply_ok": (c_int, [C.POINTER(WgradDesc)]),
     "oct_unpack_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "oct_unpack_wgrad_batch": (c_int, [c_int, C.POINTER(UnpackJob), c_void_p]),
     "oct_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,

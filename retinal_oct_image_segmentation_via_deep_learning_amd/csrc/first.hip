@@ -208,6 +208,15 @@ int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
   return rc ? rc : 1;
 }
 
+// Host query behind OctWgradArgs.dy_coef: whether oct_conv_wgrad can apply the BatchNorm backward on load
+// for this descriptor (today: the direct first-layer kernel; OCT_DISABLE_V2=1 switches it off with the
+// other pipelined kernels, and the caller then materialises dY with oct_bn_bwd_apply).
+extern "C" int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d) {
+  if (!d) return 0;
+  if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
+  return (size_t)d->n * d->h * d->w < (1u << 31) ? 1 : 0;
+}
+
 int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
   if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
   if (a->dy_coef && (!a->dy_y || !a->dy_scale || !a->dy_shift)) { oct_set_error("oct_conv_wgrad: fused apply needs y, scale, shift"); return OCT_E_INVALID; }

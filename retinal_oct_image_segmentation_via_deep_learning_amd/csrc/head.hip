@@ -117,6 +117,8 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_fwd_kernel(const HeadParams
         sp[c] += pr[c];
         sy[c] += hit ? 1.f : 0.f;
       }
+      // torch's nll_loss asserts on a target outside [0, classes); here the loss comes out as NaN (no sync needed)
+      if ((unsigned)t >= (unsigned)p.classes) ce = __builtin_nanf("");
     }
   }
   if (p.loss_partials) {
@@ -342,6 +344,7 @@ __global__ void __launch_bounds__(HEAD_THREADS) head_bwd_fused_kernel(const Head
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) lt = (c == t) ? l[c] : lt;
         ce -= lt - m - lse;
+        if ((unsigned)t >= (unsigned)p.classes) ce = __builtin_nanf("");   // out-of-range target -> NaN loss
       }
     }
     // the rest of the backward sees dlogits as stored (activation dtype), like the unfused path

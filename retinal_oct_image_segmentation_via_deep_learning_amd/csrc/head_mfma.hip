@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(HM_THREADS, 2) head_bwd_mfma_kernel(const Head
       for (int i = 0; i < 4; ++i)
         if ((4 * hh + i) == t) { lt = l[i]; mine = true; }
       if (mine && valid) ce -= lt - m - logf(s);
+      if (valid && (unsigned)t >= (unsigned)ncls) ce = __builtin_nanf("");   // out-of-range target -> NaN loss
     }
     unsigned dpk[2];
 #pragma unroll

@@ -279,11 +279,15 @@ class UNetEngine:
         if self._arena is not None and self._arena.device == dev:
             self._arena.zero_()
 
-    def _arena_end(self, dev):
+    def _flush_unpack(self):
+        """One launch that brings every weight gradient produced so far into torch layout."""
         if self._unpack_jobs:
             arr = (L.UnpackJob * len(self._unpack_jobs))(*[j[0] for j in self._unpack_jobs])
             L.check(L.lib().oct_unpack_wgrad_batch(len(self._unpack_jobs), arr, _stream()), "oct_unpack_wgrad_batch")
             self._unpack_jobs = []
+
+    def _arena_end(self, dev):
+        self._flush_unpack()
         if self._arena_short or self._arena is None:   # first step (or a larger batch): size it for the next one
             self._arena = torch.empty(self._arena_off, dtype=torch.float32, device=dev)
         self._arena_on = False
@@ -481,8 +485,11 @@ class UNetEngine:
                 G[r.cbkey].zero_()   # a bias in front of a train-mode BatchNorm cancels in (y - mean): zero gradient
         dy2 = self._bn_backward(r2, da, dpool, G, accumulate, partials=partials)
         da1, _ = self._conv_backward(r2, dy2, G, accumulate)
-        first_fused = (not need_dx and self.dtype == "bf16" and r1.src.channels == 1 and r1.src.bn0 is None
-                       and r1.cout in (16, 32, 64))
+        first_fused = False
+        if not need_dx and r1.src.c1 == 0 and r1.src.bn0 is None:
+            # the library decides (shape, dtype, OCT_DISABLE_V2): a host-side copy of that rule would drift
+            qd = L.WgradDesc(self.dt, r1.n, r1.h, r1.w, r1.src.c0, 0, r1.cout, 9, L.XF_NONE, L.XF_NONE, L.IN_PLAIN)
+            first_fused = bool(L.lib().oct_conv_wgrad_fused_apply_ok(C.byref(qd)))
         if first_fused:
             # first layer: no data gradient, so dY1 has a single consumer -- the weight-gradient kernel
             # applies the BN backward itself and the dY1 tensor is never written
@@ -494,11 +501,40 @@ class UNetEngine:
         dy1 = self._bn_backward(r1, da1, None, G, accumulate)
         return self._conv_backward(r1, dy1, G, accumulate, need_dx=need_dx)
 
+    def backward_stages(self):
+        """[(stage name, [parameter keys])] in the order backward() FINISHES their gradients: last decoder
+        block (+ head, + its up-convolution) first, first encoder block last.  This is the reverse of the
+        reference's construction order (YNet_2022.py:511-546, BioNet_2020.py:24-43), which is what lets a
+        data-parallel caller ship contiguous tail slices of a flat gradient buffer while backward continues."""
+        sp = self.spec
+
+        def blk_keys(b: BlockSpec):
+            ks = []
+            for c in (b.c1, b.c2):
+                ks += [c.w, c.bn + ".weight", c.bn + ".bias"] + ([c.b] if c.b else [])
+            return ks
+        nd = len(sp.dec)
+        stages = []
+        for di in range(nd - 1, -1, -1):
+            ks = ([sp.head_w, sp.head_b] if di == nd - 1 else []) + blk_keys(sp.dec[di]) + list(sp.ups[di][:2])
+            stages.append((f"dec{di}", ks))
+        for li in range(len(sp.enc) - 1, -1, -1):
+            stages.append((f"enc{li}", blk_keys(sp.enc[li])))
+        return stages
+
+    def _stage_done(self, hook, idx):
+        if hook is not None and idx in hook.flush_stages:
+            self._flush_unpack()        # the stage's weight gradients must be in torch layout before they leave
+            hook.stage_done(idx)
+
     def backward(self, P: dict, ctx: Ctx, G: dict, dprobs: torch.Tensor | None = None, accumulate=False,
-                 dlogits: torch.Tensor | None = None):
+                 dlogits: torch.Tensor | None = None, stage_hook=None):
         """Fills G (name -> fp32 grad tensor, torch layout) for every parameter.
         dprobs: gradient wrt the softmax output; dlogits: gradient wrt the logits (BioNet-style nets);
-        neither: gradient of the fused loss recorded by forward(target=...)."""
+        neither: gradient of the fused loss recorded by forward(target=...).
+        stage_hook (data parallel): object with `flush_stages` (indices into backward_stages()) and
+        `stage_done(idx)`, called on the launch stream's host thread as soon as every gradient of those
+        stages has been enqueued."""
         lib = L.lib()
         sp = self.spec
         self._P, self._ctx = P, ctx
@@ -583,11 +619,16 @@ class UNetEngine:
             wp = self._pack(wkey, P[wkey], L.PACK_DECONV_DGRAD, cout_d, cin_d)
             da = self._act(n, hl, wl, cin_d, dev)
             self._conv(Src(du, cout_d), wp, cin_d, 1, n, hl, wl, da, in_mode=L.IN_S2D)
+            self._stage_done(stage_hook, nd - 1 - di)
         dpool, _ = self._block_backward(sp.enc[-1].name, da, None, G, accumulate)
+        self._stage_done(stage_hook, nd)
         for li in range(len(sp.enc) - 2, -1, -1):
             # the skip of enc[li] was consumed by decode step nd-1-li
             dpool, _ = self._block_backward(sp.enc[li].name, dskip[nd - 1 - li], dpool, G, accumulate,
                                             need_dx=(li != 0))
+            if li:
+                self._stage_done(stage_hook, nd + len(sp.enc) - 1 - li)
         self._arena_end(dev)
+        self._stage_done(stage_hook, nd + len(sp.enc) - 1)   # after the last unpack launch
         self._P = self._ctx = None
         return G

@@ -41,6 +41,9 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         model = ctx.model
+        if ctx.ectx is None:
+            raise RuntimeError("Trying to backward through the HIP U-Net a second time: the saved conv outputs are "
+                               "freed by the first backward (retain_graph is not supported; run forward again)")
         names = [n for n, _ in model.named_parameters()]
         P = model._tensors()
         G = {n: torch.empty_like(P[n]) for n in names}
@@ -50,6 +53,21 @@ class _UNetFn(torch.autograd.Function):
             model._engine.backward(P, ctx.ectx, G, dlogits=dout)
         ctx.ectx = None
         return (None, None) + tuple(G[n] for n in names)
+
+
+class _EvalNoGradFn(torch.autograd.Function):
+    """eval()-mode forward under autograd: the output keeps a grad_fn, so a fine-tuning script that calls
+    .backward() through frozen BatchNorm statistics gets THIS message instead of torch's "element 0 of tensors
+    does not require grad" (the reference nn.Module would differentiate through running statistics)."""
+
+    @staticmethod
+    def forward(ctx, out, *params):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        raise NotImplementedError("backward through an eval()-mode forward (BatchNorm on running statistics) is not "
+                                  "implemented on the HIP path: call model.train() for training steps")
 
 
 class _EngineNet(nn.Module):
@@ -85,20 +103,29 @@ class _EngineNet(nn.Module):
 
     # ---- reference API ---------------------------------------------------------------------------
     def forward(self, x):
-        needs_grad = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
-        if needs_grad:
+        grad_on = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if torch.is_grad_enabled() and x.requires_grad:
+            # the reference nn.Module returns d(out)/d(x); the engine stops at the first layer's weights
+            raise NotImplementedError("gradients with respect to the network INPUT are not implemented on the HIP "
+                                      "path (x.requires_grad=True); detach the input")
+        if grad_on and self.training:
             return _UNetFn.apply(self, x, *self.parameters())
-        return self._run(x, train=self.training)
+        out = self._run(x, train=self.training)
+        if grad_on:
+            return _EvalNoGradFn.apply(out, *self.parameters())
+        return out
 
     # ---- fused extras (not in the reference) --------------------------------------
     @torch.no_grad()
-    def forward_backward(self, x, target, w_ce=1.0, w_dice=0.0, dice_eps=1e-7, want_probs=False):
+    def forward_backward(self, x, target, w_ce=1.0, w_dice=0.0, dice_eps=1e-7, want_probs=False, stage_hook=None):
         """Training step without the optimizer: forward, fused CE(+Dice) loss head, full backward.
         Writes `.grad` of every parameter and returns the device tensor [loss, ce, dice]
         (plus the probabilities when want_probs).  With w_dice == 0 (and the fused head: 32 head
         features, <= 8 classes, no probabilities requested) the Dice sums are not accumulated and the
         third entry is 0: the cross-entropy then comes out of the backward head pass and the forward
-        one is skipped."""
+        one is skipped.  stage_hook: see UNetEngine.backward (data-parallel gradient buckets).
+        A target outside [0, classes) -- where torch's nll_loss raises -- yields a NaN loss (device-side
+        flag, no synchronisation)."""
         if not self.training:
             raise RuntimeError("forward_backward needs train() mode (batch statistics)")
         P = self._tensors()
@@ -110,7 +137,7 @@ class _EngineNet(nn.Module):
             if p.grad is None:
                 p.grad = torch.empty_like(p.data)
             G[n] = p.grad
-        self._engine.backward(P, ectx, G)
+        self._engine.backward(P, ectx, G, stage_hook=stage_hook)
         return (ectx.loss, probs) if want_probs else ectx.loss
 
     @torch.no_grad()

@@ -302,3 +302,62 @@ torch.save(out, sys.argv[1])
     for k in ("g0.0/conv.weight", "g0.0/conv.bias", "g0.4/conv.weight", "g0.4/conv.bias"):
         x, y = a[k].double().flatten(), b[k].double().flatten()
         assert float((x - y).norm() / y.norm()) < 2e-2, k
+
+
+# ---- API edges where the nn.Module contract differs: loud, not silent ----------------------
+def _tiny(dtype="f32", f=8, c=3):
+    from retinal_oct_image_segmentation_via_deep_learning_amd import UNet
+    torch.manual_seed(3)
+    return UNet(1, c, init_features=f, compute_dtype=dtype).cuda()
+
+
+def test_eval_mode_backward_and_input_gradients_raise_clearly():
+    model = _tiny().eval()
+    x = torch.randn(1, 1, 32, 32, device="cuda")
+    out = model(x)                              # inference without no_grad() keeps working ...
+    assert out.grad_fn is not None
+    with pytest.raises(NotImplementedError, match="eval"):
+        out.sum().backward()                    # ... and differentiating it names the reason
+    with torch.no_grad():
+        assert model(x).grad_fn is None
+    model.train()
+    with pytest.raises(NotImplementedError, match="INPUT"):
+        model(x.clone().requires_grad_(True))
+    out = model(x)
+    out.sum().backward()
+    with pytest.raises(RuntimeError, match="second time"):
+        out.sum().backward()
+
+
+def test_out_of_range_target_gives_nan_loss():
+    """torch's nll_loss raises on a label outside [0, C); the fused head cannot raise without a sync, so the
+    loss is NaN -- on the forward head, the vector backward head and the MFMA backward head alike."""
+    x = torch.randn(1, 1, 32, 64, device="cuda")
+    for dtype, f, wd in (("f32", 8, 0.5), ("f32", 32, 0.0), ("bf16", 32, 0.0)):
+        model = _tiny(dtype, f, 3).train()
+        t = torch.randint(0, 3, (1, 32, 64), device="cuda")
+        assert torch.isfinite(model.forward_backward(x, t, 1.0, wd)[0])
+        t[0, 5, 7] = 3
+        assert torch.isnan(model.forward_backward(x, t, 1.0, wd)[0])
+        t[0, 5, 7] = -1
+        assert torch.isnan(model.loss(x, t)[0])
+
+
+def test_disable_v2_switch_runs_the_headline_width_in_bf16():
+    """OCT_DISABLE_V2=1 (generic kernels only) must still train UNet(1,C,32) in bf16: the engine
+    asks the library whether the fused first-layer weight gradient applies instead of assuming it."""
+    import subprocess
+    import sys
+    code = ("import torch; from retinal_oct_image_segmentation_via_deep_learning_amd import UNet;"
+            "torch.manual_seed(0); m = UNet(1, 4, init_features=32, compute_dtype='bf16').cuda().train();"
+            "x = torch.randn(1, 1, 32, 64, device='cuda'); t = torch.randint(0, 4, (1, 32, 64), device='cuda');"
+            "l = m.forward_backward(x, t); torch.cuda.synchronize(); assert torch.isfinite(l[0]);"
+            "assert all(torch.isfinite(p.grad).all() for p in m.parameters()); print('ok', float(l[0]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OCT_DISABLE_V2=flag, PYTHONPATH=root),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        outs[flag] = float(r.stdout.split()[-1])
+    assert abs(outs["1"] - outs["0"]) < 0.05 * abs(outs["0"])

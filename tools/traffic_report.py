@@ -6,7 +6,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest  # noqa: E402  (bench.py withholds roofline.traffic when the digest differs)
 
 root, steps = sys.argv[1], int(sys.argv[2])
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -27,4 +31,6 @@ for cls, d in tot.items():
     out[cls] = {"read_GB_per_step": round(rd / steps / 1e9, 3), "write_GB_per_step": round(wr / steps / 1e9, 3),
                 "launches_per_step": round(cnt[cls] / steps, 1),
                 "traffic_bytes_per_launch": round((rd + wr) / max(cnt[cls], 1))}
+out["csrc_digest"] = csrc_digest()
+out["command"] = "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps S --warmup W"
 print(json.dumps(out, indent=1))
