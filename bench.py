@@ -183,18 +183,25 @@ def dry_run(args, rank, world):
 
 # ---------------------------------------------------------------------------------------------------
 def cpu_baseline(args):
-    """Reference path on the host cores: cfg1 always, the cfg2 shape at batch 1."""
+    """Reference path on the host cores: cfg1 always, the cfg2 shape at batch 1.  Threads = all
+    physical cores of this box's share; when that is more than 16 the run is repeated with 16 threads (a GPU box
+    hands one GPU a 16-CPU share of a much larger host, and oversubscribed threads run slower) and the faster of
+    the two is the baseline -- both are stated."""
     from oracle import torch_unet
     cores = torch_unet.physical_cores()
-    c1 = torch_unet.time_train_steps(4, 256, 256, classes=2, iters=8, threads=cores, model="bionet", budget_s=6.0)
-    c2 = torch_unet.time_train_steps(1, args.height, args.width, args.classes, args.features, iters=5,
-                                     threads=cores, budget_s=12.0)
+    tries = [cores] + ([16] if cores > 16 else [])
+    c1 = max((torch_unet.time_train_steps(4, 256, 256, classes=2, iters=6, threads=n, model="bionet", budget_s=4.0)
+              for n in tries), key=lambda r: r["bscans_per_s_min"])
+    runs = [torch_unet.time_train_steps(1, args.height, args.width, args.classes, args.features, iters=5, threads=n,
+                                        budget_s=8.0) for n in tries]
+    c2 = max(runs, key=lambda r: r["bscans_per_s_min"])
+    others = "; ".join(f"{r['threads']} threads: min {r['s_per_iter_min']:.2f} s/iter" for r in runs if r is not c2)
     return {
         "value": round(c2["bscans_per_s_min"], 3), "unit": "B-scans/s", "cores": c2["threads"], "kind": "port",
         "sample": f"oracle/torch_unet.py (stock torch fp32 port of the reference UNet), batch 1 x {args.height}x"
-                  f"{args.width}, fwd+loss+bwd+SGD, {c2['iters']} timed iterations after 1 warm-up, all "
-                  f"{cores} physical cores of this box's share: min {c2['s_per_iter_min']:.2f} s/iter, median "
-                  f"{c2['s_per_iter_median']:.2f} s/iter",
+                  f"{args.width}, fwd+loss+bwd+SGD, {c2['iters']} timed iterations after 1 warm-up on {c2['threads']} "
+                  f"threads ({cores} physical cores visible): min {c2['s_per_iter_min']:.2f} s/iter, median "
+                  f"{c2['s_per_iter_median']:.2f} s/iter" + (f" [{others}]" if others else ""),
         "median": round(c2["bscans_per_s_median"], 3),
         "cfg1": {"value": round(c1["bscans_per_s_min"], 2), "median": round(c1["bscans_per_s_median"], 2),
                  "unit": "B-scans/s", "cores": c1["threads"],

@@ -57,3 +57,28 @@ def bio_grad_errors(z, grads, rel):
         if err > tol:
             bad.append(f"{key}: max err {err:.3e} > {tol:.3e}")
     return bad
+
+
+def ynet_case(cls, seed, in_ch, n_cls, feat, shape):
+    """cls(in_ch, n_cls, init_features=feat) under manual_seed(seed) with the BatchNorm affine parameters moved off
+    their trivial initial values -- the recipe of tools/gen_golden.py::unet_case, shared so that a network too large
+    to store (UNet(1,8,32): 31 MB of weights) is rebuilt bit-identically on both sides."""
+    torch.manual_seed(seed)
+    m = cls(in_ch, n_cls, init_features=feat)
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    B, H, W = shape
+    x = torch.randn(B, in_ch, H, W, generator=g)
+    t = torch.randint(0, n_cls, (B, H, W), generator=g)
+    return m.train(), x, t
+
+
+def grad_summary(g):
+    """[L2 norm, sum, sum of |.|] + a strided sample: what a fixture keeps of a gradient too large to store"""
+    import numpy as np
+    g = np.asarray(g, np.float64).reshape(-1)
+    return np.array([np.sqrt((g ** 2).sum()), g.sum(), np.abs(g).sum()]), g[::97].copy()

@@ -196,24 +196,45 @@ def _block_names(level):
     }[level]
 
 
-class OracleUNet:
-    """State is a dict with the reference's state_dict keys (numpy arrays)."""
+def round_bf16(a):
+    """float -> nearest bfloat16 (ties to even) -> back, on the float32 bit pattern (NaN-free inputs)."""
+    u = np.ascontiguousarray(np.asarray(a, np.float32)).view(np.uint32)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).astype(np.float64)
 
-    def __init__(self, state, dtype=np.float64):
+
+class OracleUNet:
+    """State is a dict with the reference's state_dict keys (numpy arrays).
+
+    storage=None restates the reference (every tensor in `dtype`).  storage="bf16" additionally rounds to
+    bfloat16 exactly where the HIP production path STORES a tensor in bf16 -- network input, packed conv /
+    deconv weights, raw conv outputs y (the BatchNorm statistics are taken before that rounding, from the fp32
+    accumulators), the activated tensor a conv stages, pooled tensors, deconv outputs, dlogits, every activation
+    gradient dA / dY -- and nowhere else (parameters, statistics, weight gradients and the loss stay wide).  The
+    bf16 kernels are compared with THIS model, which removes the 1 %-of-ReLU-masks-flip noise that a comparison
+    with the unrounded reference carries."""
+
+    def __init__(self, state, dtype=np.float64, storage=None):
         self.dtype = dtype
+        assert storage in (None, "bf16")
+        self.q = round_bf16 if storage == "bf16" else (lambda a: a)
         self.s = {k: (np.array(v, dtype=dtype) if np.issubdtype(np.asarray(v).dtype, np.floating)
                       else np.array(v)) for k, v in state.items()}
         self.mom = {}
 
     # -- helpers --------------------------------------------------------------------------
     def _conv_bn_relu(self, x, mod, pre, i, train, cache):
-        w = self.s[f"{mod}.{pre}conv{i}.weight"]
+        q = self.q
+        w = q(self.s[f"{mod}.{pre}conv{i}.weight"])
         gk, bk = f"{mod}.{pre}norm{i}.weight", f"{mod}.{pre}norm{i}.bias"
         rmk, rvk = f"{mod}.{pre}norm{i}.running_mean", f"{mod}.{pre}norm{i}.running_var"
         nbk = f"{mod}.{pre}norm{i}.num_batches_tracked"
-        y = conv3x3_fwd(x, w)
+        yacc = conv3x3_fwd(x, w)           # the accumulators: statistics come from these
+        y = q(yacc)                        # what is stored and re-read
         if train:
-            z, mean, var, invstd, xhat = bn_train_fwd(y, self.s[gk], self.s[bk])
+            _, mean, var, invstd, _ = bn_train_fwd(yacc, self.s[gk], self.s[bk])
+            xhat = (y - mean[None, :, None, None]) * invstd[None, :, None, None]
+            z = xhat * self.s[gk][None, :, None, None] + self.s[bk][None, :, None, None]
             n = y.shape[0] * y.shape[2] * y.shape[3]
             self.s[rmk], self.s[rvk] = bn_running_update(self.s[rmk], self.s[rvk], mean, var, n)
             self.s[nbk] = self.s[nbk] + 1
@@ -222,7 +243,8 @@ class OracleUNet:
             xhat = invstd = None
         a = np.maximum(z, 0)
         cache.append((f"{mod}.{pre}conv{i}.weight", gk, bk, x, xhat, invstd, z))
-        return a
+        self._a_wide = a                   # the head reads the activation before it is rounded for staging
+        return q(a)
 
     def _block(self, x, level, train, caches):
         mod, pre = _block_names(level)
@@ -240,7 +262,7 @@ class OracleUNet:
             raise RuntimeError("Sizes of tensors must match except in dimension 1")
         caches = {}
         skips, pools = {}, {}
-        h = x
+        h = self.q(x)
         for lv in BLOCKS_ENC:
             a = self._block(h, lv, train, caches)
             skips[lv] = a
@@ -251,11 +273,11 @@ class OracleUNet:
         for k, lv in zip([4, 3, 2, 1], ["dec4", "dec3", "dec2", "dec1"]):
             w, b = self.s[f"upconv{k}.weight"], self.s[f"upconv{k}.bias"]
             ups[k] = h
-            u = deconv2x2_fwd(h, w, b)
+            u = self.q(deconv2x2_fwd(h, self.q(w), b))
             cat = np.concatenate([u, skips[f"enc{k}"]], axis=1)  # decoder channels first (:557)
             h = self._block(cat, lv, train, caches)
         wh, bh = self.s["conv.weight"], self.s["conv.bias"]
-        logits = np.einsum("bchw,oc->bohw", h, wh[:, :, 0, 0]) + bh[None, :, None, None]
+        logits = np.einsum("bchw,oc->bohw", self._a_wide, wh[:, :, 0, 0]) + bh[None, :, None, None]
         self._cache = (caches, pools, ups, h)
         self.logits = logits
         return softmax_c(logits)
@@ -263,21 +285,24 @@ class OracleUNet:
     # -- backward from d loss / d logits ----------------------------------------------------
     def backward(self, dlogits):
         caches, pools, ups, hlast = self._cache
+        q = self.q
         g = {}
         wh = self.s["conv.weight"]
+        dlogits = q(dlogits)
         g["conv.weight"] = np.einsum("bohw,bchw->oc", dlogits, hlast)[:, :, None, None]
         g["conv.bias"] = dlogits.sum(axis=(0, 2, 3))
-        da = np.einsum("bohw,oc->bchw", dlogits, wh[:, :, 0, 0])
+        da = q(np.einsum("bohw,oc->bchw", dlogits, wh[:, :, 0, 0]))
 
         def block_bwd(level, da, need_dx=True):
             for (wk, gk, bk, xin, xhat, invstd, z) in reversed(caches[level]):
-                dz = da * (z > 0)
+                dz = q(da * (z > 0))
                 dy, dgam, dbet = bn_train_bwd(dz, xhat, self.s[gk], invstd)
+                dy = q(dy)
                 g[gk], g[bk] = dgam, dbet
                 first = wk.endswith("conv1.weight")
-                dx, dw = conv3x3_bwd(xin, self.s[wk], dy, need_dx=(need_dx or not first))
+                dx, dw = conv3x3_bwd(xin, q(self.s[wk]), dy, need_dx=(need_dx or not first))
                 g[wk] = dw
-                da = dx
+                da = q(dx) if dx is not None else None
             return da
 
         dskip = {}
@@ -285,7 +310,8 @@ class OracleUNet:
             dcat = block_bwd(lv, da)
             co = self.s[f"upconv{k}.weight"].shape[1]
             du, dskip[k] = dcat[:, :co], dcat[:, co:]
-            da, dw, db = deconv2x2_bwd(ups[k], self.s[f"upconv{k}.weight"], du)
+            da, dw, db = deconv2x2_bwd(ups[k], q(self.s[f"upconv{k}.weight"]), du)
+            da = q(da)
             g[f"upconv{k}.weight"], g[f"upconv{k}.bias"] = dw, db
         dp = block_bwd("bott", da)
         for k in [4, 3, 2, 1]:

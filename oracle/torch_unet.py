@@ -101,7 +101,8 @@ def loss_fn(probs, target, w_ce=1.0, w_dice=0.0, eps=1e-7):
 
 
 def physical_cores():
-    """Physical cores this process may run on (SMT siblings counted once; the affinity mask is the box's share)."""
+    """Physical cores this process may use: the affinity mask with SMT siblings counted once, capped by the
+    cgroup CPU quota when the container has one (a 16-CPU share of a 128-core host shows all 128 in the mask)."""
     import os
     cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     seen = set()
@@ -111,7 +112,23 @@ def physical_cores():
                 seen.add(fh.read().strip())
         except OSError:
             seen.add(str(c))
-    return max(1, len(seen))
+    n = max(1, len(seen))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        n = min(n, max(1, int(q / int(fh2.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def time_train_steps(batch, height, width, classes=8, features=32, iters=3, threads=None, model="unet",

@@ -63,7 +63,7 @@ def test_f32_matches_reference_fixture(golden_dir, name):
             else:
                 gclose(sd[k[3:]].cpu().numpy(), z[k], k, 1e-4)
     model2.eval()
-    le = model2(xd).cpu().numpy()
+    le = model2(xd).detach().cpu().numpy()   # like the reference module: requires_grad without no_grad()
     assert np.abs(le - z["logits_eval"]).max() < 2e-5 * max(1.0, float(np.abs(z["logits_eval"]).max()))
     msg = str(np.load(os.path.join(golden_dir, "bionet_api.npz"))["negative_msg"])
     with pytest.raises(RuntimeError) as ei:
@@ -110,7 +110,7 @@ def test_f32_fused_step_matches_oracle(cfg):
             assert int(sd[k]) == int(v)
     # eval mode uses the running statistics (conv bias folded into the shift)
     model.eval()
-    lg = model(x.float().cuda()).cpu().numpy()
+    lg = model(x.float().cuda()).detach().cpu().numpy()
     ref = o.forward(x.numpy(), train=False)
     assert np.abs(lg - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 

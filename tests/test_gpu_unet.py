@@ -113,29 +113,51 @@ def test_f32_sgd_trajectory(golden_dir, name):
             assert int(sd[k[3:]]) == int(z[k])
 
 
+def rel_l2(got, ref):
+    got, ref = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
+
+
+def bf16_against_rounding_aware_oracle(model, state, x, t, w_ce, w_dice, eps, tag):
+    """bf16 HIP step vs oracle/ref_cpu.OracleUNet(storage="bf16"): the same network with a bf16 rounding at every
+    point where the HIP path stores bf16.  What is left between the two is fp32-vs-fp64 accumulation order, i.e.
+    a 1-ulp difference on ~1e-4 of the stored elements -- so the bounds are per-tensor and tight, instead of the
+    cosine floor a comparison with the unrounded reference needs (bf16 flips ~1 % of the ReLU masks)."""
+    from oracle import ref_cpu
+    net = ref_cpu.OracleUNet(state, storage="bf16")
+    rp, (rl, rce, rdice), rg = net.loss_and_grads(x.numpy(), t.numpy(), w_ce, w_dice, eps)
+    loss, probs = model.forward_backward(x.cuda(), t.cuda(), w_ce, w_dice, eps, want_probs=True)
+    torch.cuda.synchronize()
+    p = probs.cpu().numpy()
+    assert np.abs(p - rp).max() < 1e-2, (tag, np.abs(p - rp).max())
+    top2 = np.sort(rp, axis=1)[:, -2:]
+    safe = (top2[:, 1] - top2[:, 0]) > 2e-2
+    assert safe.mean() > 0.5 and np.array_equal(p.argmax(1)[safe], rp.argmax(1)[safe]), tag
+    np.testing.assert_allclose(loss.cpu().numpy()[0], rl, rtol=2e-3, err_msg=tag)
+    worst = []
+    for k, prm in model.named_parameters():
+        g = prm.grad.detach().cpu().numpy()
+        if np.abs(rg[k]).max() < 1e-12:
+            continue
+        worst.append((rel_l2(g, rg[k]), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 3e-2 and np.mean([w for w, _ in worst]) < 1e-2, (tag, worst[:5])
+    return worst
+
+
 @pytest.mark.parametrize("name", CASES)
-def test_bf16_production_mode_is_close(golden_dir, name):
+def test_bf16_mode_matches_rounding_aware_oracle(golden_dir, name):
+    """the reference fixtures' networks (narrow: generic bf16 kernels)"""
     z, model = load(golden_dir, name, "bf16")
     w_ce, w_dice, lr, mom, eps = (float(v) for v in z["hyper"])
-    x, tgt = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["target"]).cuda()
-    loss, probs = model.forward_backward(x, tgt, w_ce, w_dice, eps, want_probs=True)
-    p = probs.cpu().numpy()
-    assert np.abs(p - z["probs"]).max() < 6e-2
-    top2 = np.sort(z["probs"], axis=1)[:, -2:]
-    safe = (top2[:, 1] - top2[:, 0]) > 0.08
-    if safe.any():
-        assert (p.argmax(1)[safe] == z["argmax"][safe]).mean() > 0.995
+    state = {k[3:]: z[k] for k in z.files if k.startswith("w0/")}
+    bf16_against_rounding_aware_oracle(model, state, torch.from_numpy(z["x"]), torch.from_numpy(z["target"]),
+                                       w_ce, w_dice, eps, name)
+    # and the unrounded reference stays within bf16's own noise of it
+    loss, probs = model.forward_backward(torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["target"]).cuda(),
+                                         w_ce, w_dice, eps, want_probs=True)
+    assert np.abs(probs.cpu().numpy() - z["probs"]).max() < 6e-2
     np.testing.assert_allclose(loss.cpu().numpy()[0], z["loss"][0], rtol=2e-2)
-    cos = []
-    for k in z.files:
-        if k.startswith("g0/") and z[k].size >= 16:
-            g = dict(model.named_parameters())[k[3:]].grad.cpu().numpy().ravel().astype(np.float64)
-            r = z[k].ravel().astype(np.float64)
-            cos.append(float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30)))
-    # bf16 activations flip ~1% of the ReLU masks / pooling winners relative to fp32 (forward error
-    # ~1% after 18 layers); every flip toggles a whole gradient path, so the per-tensor cosine to the
-    # fp32 reference sits around 0.9-0.97 (measured 0.78-0.97) even though the loss agrees to 1e-4.
-    assert min(cos) > 0.65 and np.mean(cos) > 0.88, (min(cos), np.mean(cos))
 
 
 @pytest.mark.parametrize("name", CASES[:2])
@@ -153,10 +175,52 @@ def test_bf16_sgd_trajectory_descends_like_reference(golden_dir, name):
     assert losses[-1] < losses[0]
 
 
-def test_default_width_network_matches_oracle_and_bf16_tracks_f32():
-    """init_features = 32 (the BASELINE configuration) takes kernel paths the small fixtures do not:
-    the fused head backward (feat == 32) and, in bf16, the pipelined conv / wgrad / first-layer
-    kernels.  fp32 mode is checked against the fp64 oracle, bf16 mode against fp32 mode."""
+def _wide_fixture(golden_dir):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("test_oracle_helpers", os.path.join(os.path.dirname(__file__), "test_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.wide_case(golden_dir), mod.wide_grad_errors
+
+
+def test_headline_width_f32_matches_reference_fixture(golden_dir):
+    """UNet(1, 8, init_features=32) -- the benchmarked network -- in fp32 parity mode against the fixture
+    tools/gen_golden_wide.py recorded from the reference module (run in float64)."""
+    (z, state, x, t, model), grad_errors = _wide_fixture(golden_dir)
+    model = model.cuda().train().set_compute_dtype("f32")
+    loss, probs = model.forward_backward(x.cuda(), t.cuda(), want_probs=True)
+    torch.cuda.synchronize()
+    p = probs.cpu().numpy()
+    assert np.abs(p - z["probs"]).max() < 2e-5
+    top2 = np.sort(z["probs"], axis=1)[:, -2:]
+    safe = (top2[:, 1] - top2[:, 0]) > 1e-5
+    assert safe.mean() > 0.999 and np.array_equal(p.argmax(1)[safe], z["argmax"][safe])
+    np.testing.assert_allclose(loss[0].item(), float(z["loss"]), rtol=2e-5)
+    grads = {k: prm.grad.detach().cpu().numpy() for k, prm in model.named_parameters()}
+    # a handful of the 3.5 M ReLU inputs sit within fp32 rounding of zero (fixture: min |z| = 1.4e-6): the deep,
+    # small gradients may move by a flipped mask or two -- 2e-2 of the tensor's max still convicts a wrong tap
+    assert not grad_errors(z, grads, 2e-2)
+
+
+def test_headline_width_bf16_production_kernels_match_rounding_aware_oracle(golden_dir):
+    """The kernels bench.py times (igemm2 / wgrad2 / first / head_mfma) end to end, per tensor, against the
+    rounding-aware oracle, on the reference-pinned wide fixture's weights (64 x 128) and on 128 x 256."""
+    (z, state, x, t, model), _ = _wide_fixture(golden_dir)
+    model = model.cuda().train().set_compute_dtype("bf16")
+    bf16_against_rounding_aware_oracle(model, state, x, t, 1.0, 0.0, 1e-7, "wide fixture 2x64x128, CE (deferred head)")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.cuda()
+    bf16_against_rounding_aware_oracle(model, state, x, t, 1.0, 0.25, 1e-7, "wide fixture 2x64x128, CE + Dice")
+    g = torch.Generator().manual_seed(12)
+    x2 = torch.randn(2, 1, 128, 256, generator=g)
+    t2 = torch.randint(0, 8, (2, 128, 256), generator=g)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.cuda()
+    bf16_against_rounding_aware_oracle(model, state, x2, t2, 1.0, 0.0, 1e-7, "2x128x256")
+
+
+def test_default_width_network_matches_oracle_in_f32():
+    """init_features = 32 takes the fused head backward (feat == 32); fp32 mode against the fp64 oracle."""
     from oracle import ref_cpu
     from retinal_oct_image_segmentation_via_deep_learning_amd import UNet
     torch.manual_seed(11)
@@ -170,27 +234,8 @@ def test_default_width_network_matches_oracle_and_bf16_tracks_f32():
     rp, (rl, _, _), rg = net.loss_and_grads(x.numpy(), t.numpy(), 1.0, 0.25)
     assert np.abs(probs.cpu().numpy() - rp).max() < 2e-5
     np.testing.assert_allclose(loss[0].item(), rl, rtol=2e-5)
-    g32 = {}
     for k, p in model.named_parameters():
-        g32[k] = p.grad.detach().cpu().numpy().copy()
-        grad_close(g32[k], rg[k], k, 3e-3)
-    # bf16 on a regular shape (W % 32 == 0, H % 16 == 0 at every level would need 512 px; here the
-    # full-resolution and half-resolution levels are regular, deeper ones fall back to the generic kernels)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
-    model.cuda().set_compute_dtype("bf16")
-    x2 = torch.randn(2, 1, 128, 256, generator=g).cuda()
-    t2 = torch.randint(0, 8, (2, 128, 256), generator=g).cuda()
-    l16 = model.forward_backward(x2, t2, 1.0, 0.25).cpu().numpy()
-    g16 = {k: p.grad.detach().double().cpu().numpy().ravel() for k, p in model.named_parameters()}
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
-    model.cuda().set_compute_dtype("f32")
-    l32 = model.forward_backward(x2, t2, 1.0, 0.25).cpu().numpy()
-    np.testing.assert_allclose(l16, l32, rtol=5e-3)
-    cos = []
-    for k, p in model.named_parameters():
-        a, b = g16[k], p.grad.detach().double().cpu().numpy().ravel()
-        cos.append(float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)))
-    assert min(cos) > 0.6 and np.mean(cos) > 0.88, (min(cos), np.mean(cos))
+        grad_close(p.grad.detach().cpu().numpy(), rg[k], k, 3e-3)
 
 
 def test_api_errors_like_reference(golden_dir):

@@ -171,3 +171,79 @@ def test_bionet_unet_oracle_matches_torch_restatement():
     np.testing.assert_allclose(o.forward(x.numpy(), train=False), m(x).detach().numpy(), rtol=1e-9, atol=1e-9)
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
         o.forward(np.zeros((1, 1, 20, 16)))
+
+
+# ---- the headline width: UNet(1, 8, init_features=32), fixture made from the reference by tools/gen_golden_wide.py ----
+WIDE = "unet_c8_f32_2x64x128_wide"
+
+
+def wide_case(golden_dir):
+    """(fixture, state_dict as numpy, x, target): the weights are rebuilt from the seed with the drop-in's own class
+    (same construction order as the reference => same tensors) and verified against the reference's checksums."""
+    import torch
+    from oracle.cases import ynet_case
+    from retinal_oct_image_segmentation_via_deep_learning_amd import UNet
+    z = np.load(os.path.join(golden_dir, WIDE + ".npz"))
+    in_ch, ncls, feat, b, h, w = (int(v) for v in z["meta"])
+    model, x, t = ynet_case(UNet, int(z["seed"]), in_ch, ncls, feat, (b, h, w))
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z["keys"]]
+    for k, v in sd.items():
+        v = v.double()
+        np.testing.assert_allclose([float(v.sum()), float(v.abs().sum())], z["wsum/" + k], rtol=1e-12, atol=1e-12, err_msg=k)
+    assert np.array_equal(x.numpy(), z["x"]) and np.array_equal(t.numpy(), z["target"])
+    return z, {k: v.detach().numpy().copy() for k, v in sd.items()}, x, t, model
+
+
+def wide_grad_errors(z, grads, rel):
+    """failures of a {name: ndarray} gradient set against the fixture's full tensors / (norms, strided sample)"""
+    from oracle.cases import grad_summary
+    bad = []
+    for key in z.files:
+        kind, _, name = key.partition("/")
+        if kind == "g":
+            ref, got = z[key].astype(np.float64), np.asarray(grads[name], np.float64)
+        elif kind == "gs":
+            ref, got = z[key], grad_summary(grads[name])[1]
+        elif kind == "gn":
+            ref, got = z[key][:1], grad_summary(grads[name])[0][:1]
+        else:
+            continue
+        tol = rel * max(float(np.abs(ref).max()), 1e-5)
+        err = float(np.abs(got - ref).max())
+        if err > tol:
+            bad.append(f"{key}: max err {err:.3e} > {tol:.3e}")
+    return bad
+
+
+def test_wide_unet_oracle_matches_reference_fixture(golden_dir):
+    z, state, x, t, _ = wide_case(golden_dir)
+    net = ref_cpu.OracleUNet(state)
+    probs, (loss, _, _), grads = net.loss_and_grads(x.numpy(), t.numpy())
+    # the fixture is the reference module run in float64 on the same fp32 weights: agreement to round-off
+    np.testing.assert_allclose(probs, z["probs"], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(probs.argmax(1), z["argmax"])
+    np.testing.assert_allclose(loss, float(z["loss"]), rtol=1e-12)
+    assert not wide_grad_errors(z, grads, 1e-8)
+    for k in z.files:
+        if k.startswith("b1/"):
+            np.testing.assert_allclose(net.s[k[3:]], z[k], rtol=1e-10, atol=1e-12, err_msg=k)
+
+
+def test_bf16_storage_mode_rounds_and_stays_close(golden_dir):
+    """storage="bf16" is the same restatement with roundings at the HIP path's storage points: every stored tensor
+    is representable in bf16, and the result stays within bf16 noise of the wide model (sanity of the mode itself;
+    the kernels are compared against it in tests/test_gpu_unet.py)."""
+    z, w0 = load_case(golden_dir, CASES[0])
+    wide = ref_cpu.OracleUNet(w0)
+    pw, (lw, _, _), gw = wide.loss_and_grads(z["x"], z["target"])
+    net = ref_cpu.OracleUNet(w0, storage="bf16")
+    p, (l, _, _), g = net.loss_and_grads(z["x"], z["target"])
+    for lvl, c in net._cache[0].items():
+        for (_, _, _, xin, _, _, _) in c:
+            assert np.array_equal(ref_cpu.round_bf16(xin), xin), lvl      # staged activations are bf16 values
+    assert np.abs(p - pw).max() < 5e-2 and abs(l - lw) < 2e-2 * abs(lw)
+    cos = [float(g[k].ravel() @ gw[k].ravel() / (np.linalg.norm(g[k]) * np.linalg.norm(gw[k]) + 1e-30)) for k in g if g[k].size >= 16]
+    assert np.mean(cos) > 0.85        # same regime the bf16 kernels showed against fp32 in round 1 (mask flips)
+    x = np.array([1.0, 1.00390625, 1.005859375, -3.14159, 1e-40, 65504.0])
+    assert np.array_equal(ref_cpu.round_bf16(x)[:3], [1.0, 1.0, 1.0078125])    # ties to even, then above the tie
