@@ -316,6 +316,15 @@ int oct_confusion_counts(const void* y_true, const void* y_pred, int elem, size_
                          int64_t* out_i /* [6] device, zeroed by callee */,
                          double* out_f /* [6] device, zeroed by callee */, void* stream);
 
+/* Per-class variant for CLASS MAPS (integer element types only): out[c][6] holds the same six sums for the
+ * one-vs-rest masks (y_true == c), (y_pred == c), c = 0..classes-1 (classes <= 16), all classes in ONE pass --
+ * what the reference's functions (Region_based_metrics.py:3-61, ConfusionMatrix_based_metrics.py:4-63) compute
+ * when they are called once per class on binarised maps.  Labels outside [0, classes) belong to no class.
+ * scratch: 48 x uint64 device words (zeroed by the callee).                                               */
+int oct_class_confusion_counts(const void* y_true, const void* y_pred, int elem, size_t n, int classes,
+                               int64_t* out /* [classes][6] device */, uint64_t* scratch /* [48] device */,
+                               void* stream);
+
 /* Metrics/PixelError_based_metrics.py:3-37: out[0] = sum (double(t) - double(p))^2 (device double)      */
 int oct_sqdiff_sum(const void* y_true, const void* y_pred, int elem, size_t n, double* out, void* stream);
 /* Metrics/Biomarker_based_metrics.py:3-21: out[0] = sum over columns of |colsum(t) - colsum(p)| for a

@@ -217,7 +217,13 @@ class OracleUNet:
     def __init__(self, state, dtype=np.float64, storage=None):
         self.dtype = dtype
         assert storage in (None, "bf16")
-        self.q = round_bf16 if storage == "bf16" else (lambda a: a)
+        if storage == "bf16":
+            # rounded values come back in `dtype`: with dtype=float32 the contractions accumulate in fp32 like the
+            # MFMA accumulators do (in numpy's blocked order, not the kernel's)
+            self.q = (lambda a: round_bf16(a).astype(dtype)) if dtype != np.float64 else round_bf16
+        else:
+            self.q = lambda a: a
+        self.trace = None                  # set to a dict to keep the stored conv outputs / gradients per layer
         self.s = {k: (np.array(v, dtype=dtype) if np.issubdtype(np.asarray(v).dtype, np.floating)
                       else np.array(v)) for k, v in state.items()}
         self.mom = {}
@@ -243,6 +249,8 @@ class OracleUNet:
             xhat = invstd = None
         a = np.maximum(z, 0)
         cache.append((f"{mod}.{pre}conv{i}.weight", gk, bk, x, xhat, invstd, z))
+        if self.trace is not None:
+            self.trace["y:" + f"{mod}.{pre}conv{i}.weight"] = y
         self._a_wide = a                   # the head reads the activation before it is rounded for staging
         return q(a)
 
@@ -266,7 +274,10 @@ class OracleUNet:
         for lv in BLOCKS_ENC:
             a = self._block(h, lv, train, caches)
             skips[lv] = a
-            h, idx = maxpool2x2_fwd(a)
+            # the pooling kernel compares the activations BEFORE they are rounded for storage (two neighbours that
+            # share a bf16 bucket do not tie), and the backward routing re-derives the same winner from y
+            h, idx = maxpool2x2_fwd(self._a_wide)
+            h = self.q(h)
             pools[lv] = (idx, a.shape)
         h = self._block(h, "bott", train, caches)
         ups = {}
@@ -298,6 +309,8 @@ class OracleUNet:
                 dz = q(da * (z > 0))
                 dy, dgam, dbet = bn_train_bwd(dz, xhat, self.s[gk], invstd)
                 dy = q(dy)
+                if self.trace is not None:
+                    self.trace["g:" + wk], self.trace["dy:" + wk] = dz, dy
                 g[gk], g[bk] = dgam, dbet
                 first = wk.endswith("conv1.weight")
                 dx, dw = conv3x3_bwd(xin, q(self.s[wk]), dy, need_dx=(need_dx or not first))

@@ -121,6 +121,7 @@ SIGNATURES = {
     "oct_gate_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oct_gate_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oct_confusion_counts": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "oct_class_confusion_counts": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "oct_sqdiff_sum": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
     "oct_column_absdiff_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
 }
