@@ -85,6 +85,8 @@ typedef struct OctConvDesc {
   int in_mode, out_mode;
   int split;         /* OUT_PLAIN: channels [0,split) -> y0, [split,cout) -> y1; 0: all to y0 */
   int want_stats;    /* write per-workgroup partial sum / sum of squares of the fp32 outputs */
+  int kh, kw;        /* kernel size; 0, 0 = derive from taps (9 -> 3x3, 1 -> 1x1).  7, 3 with taps = 21 is ReLayNet's
+                      * BasicBlock conv (ReLayNet_2017.py:155-160): stride 1, padding ((kh-1)/2, (kw-1)/2), plain in/out */
 } OctConvDesc;
 
 typedef struct OctConvArgs {
@@ -103,6 +105,10 @@ int oct_conv_stat_blocks(const OctConvDesc* d);
  * rows, `taps` taps and `kch` input channels */
 size_t oct_packed_weight_elems(int rows, int taps, int kch);
 int oct_pack_weights(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, void* stream);
+/* OCT_PACK_CONV_FPROP / OCT_PACK_CONV_DGRAD of a (Cout,Cin,kh,kw) weight with any odd kernel size up to 7x7
+ * (buffer: oct_packed_weight_elems(rows, kh*kw, kch)); ReLayNet_2017.py:155-160 uses 7x3.                  */
+int oct_pack_weights_kk(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int kh, int kw,
+                        void* stream);
 /* The same for up to OCT_PACK_BATCH_MAX weights per launch (all re-packings that follow an optimizer
  * step in one go); longer lists are split.  Jobs are plain structs read on the host.              */
 #define OCT_PACK_BATCH_MAX 96
@@ -126,6 +132,7 @@ typedef struct OctWgradDesc {
   int taps;
   int xform0, xform1;
   int dy_mode;
+  int kh, kw;        /* as in OctConvDesc; dwp is [kh*kw][cout][ktot] */
 } OctWgradDesc;
 typedef struct OctWgradArgs {
   const void* x0; const void* x1;
@@ -146,6 +153,8 @@ int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d);
  * OCT_PACK_DECONV_FPROP (grad[ci][co][dydx]) or OCT_PACK_1X1_FPROP (grad[co][ci]).
  * accumulate != 0: grad += */
 int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cout, int cin, int accumulate, void* stream);
+/* dwp[kh*kw][cout][cin] -> grad (Cout,Cin,kh,kw) for any kernel size */
+int oct_unpack_wgrad_kk(const float* dwp, float* grad, int cout, int cin, int kh, int kw, int accumulate, void* stream);
 /* The same for up to OCT_PACK_BATCH_MAX gradients per launch (a whole backward pass).               */
 typedef struct OctUnpackJob {
   int mode, cout, cin, accumulate;
@@ -305,6 +314,25 @@ int oct_space_to_depth(int dtype, const void* in, void* out, int n, int h, int w
 int oct_gate_fwd(int dtype, const void* x, const void* p, void* out, size_t npix, int c, void* stream);
 int oct_gate_bwd(int dtype, const void* dout, const void* x, const void* p, void* dx, void* dp,
                  size_t npix, int c, void* stream);
+
+/* ReLayNet blocks (SOTAS/Lesions_Segment/ReLayNet_2017.py:133-201).
+ * BasicBlock :164-168: out = prelu(bn(conv7x3(x))) with nn.PReLU()'s single learnable slope `alpha` (device float[1]):
+ *   forward  out = z > 0 ? z : alpha*z,  z = y*scale[c] + shift[c]  (y = raw conv output, scale/shift from oct_bn_finalize)
+ *   backward dz = dout * (z > 0 ? 1 : alpha);  dalpha[0] += sum dout*z*[z <= 0]  (caller zeroes dalpha); dz may alias dout */
+int oct_affine_prelu_fwd(int dtype, const void* y, const float* scale, const float* shift, const float* alpha,
+                         void* out, size_t npix, int c, void* stream);
+int oct_affine_prelu_bwd(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
+                         const float* alpha, void* dz, float* dalpha, size_t npix, int c, void* stream);
+/* EncoderBlock :174-179, nn.MaxPool2d(k, k, return_indices=True): out (n,h/k,w/k,c) and idx (same shape, int64) holding
+ * torch's index of the winner inside its (n, c) input plane, iy*w + ix; first maximum in row-major window order.      */
+int oct_maxpool_idx_fwd(int dtype, const void* a, void* out, int64_t* idx, int n, int h, int w, int c, int k, void* stream);
+/* DecoderBlock :185-188, nn.MaxUnpool2d: out[n, idx[n,p,c], c] = v[n,p,c] over a zero-filled (by the caller) out of
+ * `plane` = H*W pixels per image (also the backward of the pooling above); the gather is its transpose (unpool
+ * backward): v[n,p,c] = x[n, idx[n,p,c], c].  npool = pooled pixels per image.  Out-of-range indices are skipped / 0. */
+int oct_index_scatter(int dtype, const void* v, const int64_t* idx, void* out, int n, size_t npool, size_t plane, int c,
+                      void* stream);
+int oct_index_gather(int dtype, const void* x, const int64_t* idx, void* v, int n, size_t npool, size_t plane, int c,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Metrics (Metrics/Region_based_metrics.py:3-61, Metrics/ConfusionMatrix_based_metrics.py:4-63)

@@ -18,6 +18,7 @@ DT_BF16, DT_F32 = 0, 1
 XF_NONE, XF_AFFINE_RELU = 0, 1
 IN_PLAIN, IN_S2D = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT_PRELU = 3   # host-side tag only: PReLU has its own entry points (oct_affine_prelu_fwd / _bwd)
 OUT_PLAIN, OUT_D2S = 0, 1
 PACK_CONV_FPROP, PACK_CONV_DGRAD, PACK_DECONV_FPROP, PACK_DECONV_DGRAD, PACK_1X1_DGRAD, PACK_1X1_FPROP = range(6)
 MAX_CLASSES = 16
@@ -42,7 +43,7 @@ PACK_BATCH_MAX = 96
 class ConvDesc(C.Structure):
     _fields_ = [(k, c_int) for k in (
         "dtype", "n", "h", "w", "c0", "c1", "cout", "taps", "xform0", "xform1", "in_mode", "out_mode",
-        "split", "want_stats")]
+        "split", "want_stats", "kh", "kw")]
 
 
 class ConvArgs(C.Structure):
@@ -52,7 +53,7 @@ class ConvArgs(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [(k, c_int) for k in (
-        "dtype", "n", "h", "w", "c0", "c1", "cout", "taps", "xform0", "xform1", "dy_mode")]
+        "dtype", "n", "h", "w", "c0", "c1", "cout", "taps", "xform0", "xform1", "dy_mode", "kh", "kw")]
 
 
 class WgradArgs(C.Structure):
@@ -74,6 +75,14 @@ SIGNATURES = {
     "oct_conv_stat_blocks": (c_int, [C.POINTER(ConvDesc)]),
     "oct_packed_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "oct_pack_weights": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "oct_pack_weights_kk": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_unpack_wgrad_kk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_affine_prelu_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oct_affine_prelu_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                     c_int, c_void_p]),
+    "oct_maxpool_idx_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_index_scatter": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_int, c_void_p]),
+    "oct_index_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_int, c_void_p]),
     "oct_pack_weights_batch": (c_int, [c_int, c_int, C.POINTER(PackJob), c_void_p]),
     "oct_conv_forward": (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvArgs), c_void_p]),
     "oct_conv_wgrad": (c_int, [C.POINTER(WgradDesc), C.POINTER(WgradArgs), c_void_p]),

@@ -415,3 +415,150 @@ extern "C" int oct_gate_bwd(int dtype, const void* dout, const void* x, const vo
     OCT_CHECK(false, "oct_gate_bwd: bad dtype");
   return oct_check_launch("gate_bwd");
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// ReLayNet_2017.py:133-201 building blocks: BatchNorm + PReLU (one learnable slope, nn.PReLU() default),
+// MaxPool2d(return_indices=True) and MaxUnpool2d.
+// ---------------------------------------------------------------------------------------------
+// out = z > 0 ? z : alpha*z with z = y*scale[c] + shift[c]   (BasicBlock.forward :164-168)
+template <typename T, int V>
+__global__ void affine_prelu_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                        const float* __restrict__ alpha, T* __restrict__ out, size_t npix, int c) {
+  const int G = c / V;
+  const size_t total = npix * G;
+  const float al = alpha[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = i % G; const size_t off = (i / G) * c + g * V;
+    float sc[V], sh[V], v[V];
+    load_vec<float, V>(scale + g * V, sc); load_vec<float, V>(shift + g * V, sh);
+    load_vec<T, V>(y + off, v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) { const float z = fmaf(v[j], sc[j], sh[j]); v[j] = z > 0.f ? z : al * z; }
+    store_vec<T, V>(out + off, v);
+  }
+}
+extern "C" int oct_affine_prelu_fwd(int dtype, const void* y, const float* scale, const float* shift, const float* alpha,
+                                    void* out, size_t npix, int c, void* stream) {
+  OCT_CHECK(y && scale && shift && alpha && out && npix > 0 && c > 0, "oct_affine_prelu_fwd: bad args");
+  const int v = bk_vec(c);
+  const int blocks = bk_blocks(npix * (c / v));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, V) hipLaunchKernelGGL((affine_prelu_fwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)y, \
+                                        scale, shift, alpha, (T*)out, npix, c)
+  BK_DISPATCH("oct_affine_prelu_fwd");
+#undef LAUNCH
+  return oct_check_launch("affine_prelu_fwd");
+}
+// dz = dout * (z > 0 ? 1 : alpha); dalpha += sum dout * z * [z <= 0]   (ATen's prelu backward: the slope branch at z == 0);
+// z is recomputed from the stored raw conv output.  dalpha: one fp32 atomic per wave.
+template <typename T, int V>
+__global__ void affine_prelu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ y, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, const float* __restrict__ alpha, T* __restrict__ dz,
+                                        float* __restrict__ dalpha, size_t npix, int c) {
+  const int G = c / V;
+  const size_t total = npix * G;
+  const float al = alpha[0];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = i % G; const size_t off = (i / G) * c + g * V;
+    float sc[V], sh[V], v[V], d[V];
+    load_vec<float, V>(scale + g * V, sc); load_vec<float, V>(shift + g * V, sh);
+    load_vec<T, V>(y + off, v); load_vec<T, V>(dout + off, d);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float z = fmaf(v[j], sc[j], sh[j]);
+      if (z > 0.f) { /* identity branch */ } else { acc = fmaf(d[j], z, acc); d[j] *= al; }
+    }
+    store_vec<T, V>(dz + off, d);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(dalpha, acc);
+}
+extern "C" int oct_affine_prelu_bwd(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
+                                    const float* alpha, void* dz, float* dalpha, size_t npix, int c, void* stream) {
+  OCT_CHECK(dout && y && scale && shift && alpha && dz && dalpha && npix > 0 && c > 0, "oct_affine_prelu_bwd: bad args");
+  const int v = bk_vec(c);
+  const int blocks = bk_blocks(npix * (c / v));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, V) hipLaunchKernelGGL((affine_prelu_bwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)dout, \
+                                        (const T*)y, scale, shift, alpha, (T*)dz, dalpha, npix, c)
+  BK_DISPATCH("oct_affine_prelu_bwd");
+#undef LAUNCH
+  return oct_check_launch("affine_prelu_bwd");
+}
+
+// MaxPool2d(k, stride k, return_indices=True) (EncoderBlock :174-179): pooled value + torch's index convention,
+// iy*W + ix inside the (n, c) plane of the INPUT; first maximum in row-major window order.  idx is NHWC like out.
+template <typename T, int V>
+__global__ void maxpool_idx_fwd_kernel(const T* __restrict__ a, T* __restrict__ out, long long* __restrict__ idx, int n, int ho,
+                                       int wo, int c, int k) {
+  const int G = c / V;
+  const size_t total = (size_t)n * ho * wo * G;
+  const int w = wo * k, h = ho * k;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = i % G; size_t p = i / G;
+    const int xo = p % wo; p /= wo; const int yo = p % ho; const int img = p / ho;
+    float m[V]; int arg[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { m[j] = -INFINITY; arg[j] = (yo * k) * w + xo * k; }
+    for (int q = 0; q < k * k; ++q) {
+      const int iy = yo * k + q / k, ix = xo * k + q % k;
+      float v[V];
+      load_vec<T, V>(a + (((size_t)img * h + iy) * w + ix) * c + g * V, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) if (v[j] > m[j]) { m[j] = v[j]; arg[j] = iy * w + ix; }
+    }
+    const size_t o = (((size_t)img * ho + yo) * wo + xo) * c + g * V;
+    store_vec<T, V>(out + o, m);
+#pragma unroll
+    for (int j = 0; j < V; ++j) idx[o + j] = arg[j];
+  }
+}
+extern "C" int oct_maxpool_idx_fwd(int dtype, const void* a, void* out, int64_t* idx, int n, int h, int w, int c, int k,
+                                   void* stream) {
+  OCT_CHECK(a && out && idx && n > 0 && c > 0 && k > 0 && h > 0 && w > 0 && h % k == 0 && w % k == 0, "oct_maxpool_idx_fwd: bad args");
+  const int v = bk_vec(c);
+  const int blocks = bk_blocks((size_t)n * (h / k) * (w / k) * (c / v));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, V) hipLaunchKernelGGL((maxpool_idx_fwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)a, \
+                                        (T*)out, (long long*)idx, n, h / k, w / k, c, k)
+  BK_DISPATCH("oct_maxpool_idx_fwd");
+#undef LAUNCH
+  return oct_check_launch("maxpool_idx_fwd");
+}
+// scatter (MaxUnpool2d forward :185-188, and max-pool backward): out[n, idx, c] = v[n, p, c], zero elsewhere.  `out` must be
+// zero-filled by the caller; an index outside [0, h*w) is skipped.  The pooled grid may be any (hp, wp): indices decide.
+// gather (MaxUnpool2d backward, max-pool forward re-read): v[n, p, c] = x[n, idx, c].
+template <typename T, bool SCATTER>
+__global__ void index_move_kernel(const T* __restrict__ src, const long long* __restrict__ idx, T* __restrict__ dst, int n,
+                                  size_t npool, size_t plane, int c) {
+  const size_t total = (size_t)n * npool * c;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = i % c; const size_t img = i / ((size_t)npool * c);
+    const long long q = idx[i];
+    if (q < 0 || (size_t)q >= plane) { if (!SCATTER) dst[i] = from_f32<T>(0.f); continue; }
+    const size_t big = (img * plane + (size_t)q) * c + ch;
+    if (SCATTER) dst[big] = src[i]; else dst[i] = src[big];
+  }
+}
+extern "C" int oct_index_scatter(int dtype, const void* v, const int64_t* idx, void* out, int n, size_t npool, size_t plane,
+                                 int c, void* stream) {
+  OCT_CHECK(v && idx && out && n > 0 && npool > 0 && plane > 0 && c > 0, "oct_index_scatter: bad args");
+  const int blocks = bk_blocks((size_t)n * npool * c);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OCT_DT_BF16) hipLaunchKernelGGL((index_move_kernel<bf16_t, true>), dim3(blocks), dim3(BK_THREADS), 0, s, (const bf16_t*)v, (const long long*)idx, (bf16_t*)out, n, npool, plane, c);
+  else if (dtype == OCT_DT_F32) hipLaunchKernelGGL((index_move_kernel<float, true>), dim3(blocks), dim3(BK_THREADS), 0, s, (const float*)v, (const long long*)idx, (float*)out, n, npool, plane, c);
+  else OCT_CHECK(false, "oct_index_scatter: bad dtype");
+  return oct_check_launch("index_scatter");
+}
+extern "C" int oct_index_gather(int dtype, const void* x, const int64_t* idx, void* v, int n, size_t npool, size_t plane,
+                                int c, void* stream) {
+  OCT_CHECK(x && idx && v && n > 0 && npool > 0 && plane > 0 && c > 0, "oct_index_gather: bad args");
+  const int blocks = bk_blocks((size_t)n * npool * c);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OCT_DT_BF16) hipLaunchKernelGGL((index_move_kernel<bf16_t, false>), dim3(blocks), dim3(BK_THREADS), 0, s, (const bf16_t*)x, (const long long*)idx, (bf16_t*)v, n, npool, plane, c);
+  else if (dtype == OCT_DT_F32) hipLaunchKernelGGL((index_move_kernel<float, false>), dim3(blocks), dim3(BK_THREADS), 0, s, (const float*)x, (const long long*)idx, (float*)v, n, npool, plane, c);
+  else OCT_CHECK(false, "oct_index_gather: bad dtype");
+  return oct_check_launch("index_gather");
+}

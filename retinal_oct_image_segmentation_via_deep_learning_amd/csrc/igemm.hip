@@ -126,20 +126,25 @@ __device__ __forceinline__ void store4(const IgemmParams& p, int img, int oy, in
   }
 }
 
-template <typename T, int TAPS, int WM, int WN, int MF, int NF, int KC>
+// KH x KW kernel, stride 1, "same" padding ((KH-1)/2, (KW-1)/2): 3x3 and 1x1 for the U-Nets, 7x3 for ReLayNet's
+// BasicBlock (ReLayNet_2017.py:155-160).  tap = ky*KW + kx in the packed weights.
+template <typename T, int KH, int KW, int WM, int WN, int MF, int NF, int KC>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
+  constexpr int TAPS = KH * KW;
   constexpr int TH = WM * MF, TW = 32;
-  constexpr int HALO = (TAPS == 9) ? 1 : 0;
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr int HALO_H = (KH - 1) / 2, HALO_W = (KW - 1) / 2;
+  constexpr int LH = TH + KH - 1, LW = TW + KW - 1;
   constexpr int PIXB = KC * (int)sizeof(T) + 16;  // LDS bytes per pixel (+16: conflict-free b128 reads)
   constexpr int NT = WN * NF * 32;
   constexpr int GROUPS = KC / 8;
   typedef Mma<T> M;
   typedef typename M::Frag Frag;
 
-  __shared__ __attribute__((aligned(16))) unsigned char tile[LH * LW * PIXB];
-  __shared__ float wg_stats[WM][2][NT];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ig_smem[];   // halo tile, then [WM][2][NT] statistics
+  unsigned char* const tile = ig_smem;
+  float (*const wg_stats)[2][NT] = reinterpret_cast<float (*)[2][NT]>(ig_smem + LH * LW * PIXB);
+  static_assert((LH * LW * PIXB) % 16 == 0, "statistics scratch stays aligned");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -166,7 +171,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     for (int idx = tid; idx < LH * LW * GROUPS; idx += 256) {
       const int pix = idx / GROUPS, grp = idx - pix * GROUPS;
       const int ly = pix / LW, lx = pix - ly * LW;
-      const int iy = y0 + ly - HALO, ix = x0 + lx - HALO;
+      const int iy = y0 + ly - HALO_H, ix = x0 + lx - HALO_W;
       float v[8];
       if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
         fetch8<T>(p, img, iy, ix, ch * KC + grp * 8, v);
@@ -178,9 +183,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     }
     __syncthreads();
     // ---- MFMA over taps x k16 steps ----
-#pragma unroll
+    constexpr int TAP_UNROLL = TAPS <= 9 ? TAPS : 1;   // 21 taps x 2 steps x 8 fragment pairs: keep the big kernels rolled
+#pragma unroll TAP_UNROLL
     for (int tap = 0; tap < TAPS; ++tap) {
-      const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
+      const int ty = tap / KW, tx = tap % KW;
 #pragma unroll
       for (int k16 = 0; k16 < KC / 16; ++k16) {
         const int kk = ch * (KC / 16) + k16;
@@ -273,6 +279,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 
 // ---- weight packing -----------------------------------------------------------------------------
 // wp[((nb*TAPS + tap)*nk16 + kk)*512 + lane*8 + j] = A[row = nb*32 + (lane&31)][tap][k = kk*16 + 8*(lane>>5) + j]
+// mode OCT_PACK_CONV_FPROP / _DGRAD with taps = kh*kw of any kernel size (torch layout (Cout,Cin,kh,kw)): the dgrad
+// filter is the point reflection of the kernel, i.e. the reversed flat tap index
 template <typename T>
 __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, T* __restrict__ wp, int cout, int cin,
                                     int rows, int taps, int kch, int nk16, size_t total) {
@@ -288,9 +296,9 @@ __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, T* __
     float v = 0.f;
     if (row < rows && k < kch) {
       if (mode == OCT_PACK_CONV_FPROP) {            // row = co, k = ci
-        v = w[((size_t)row * cin + k) * 9 + tap];
+        v = w[((size_t)row * cin + k) * taps + tap];
       } else if (mode == OCT_PACK_CONV_DGRAD) {     // row = ci, k = co, flipped tap
-        v = w[((size_t)k * cin + row) * 9 + (8 - tap)];
+        v = w[((size_t)k * cin + row) * taps + (taps - 1 - tap)];
       } else if (mode == OCT_PACK_DECONV_FPROP) {   // row = dydx*cout + co, k = ci
         const int dydx = row / cout, co = row - dydx * cout;
         v = w[((size_t)k * cout + co) * 4 + dydx];
@@ -322,11 +330,22 @@ extern "C" size_t oct_packed_weight_elems(int rows, int taps, int kch) {
   return (size_t)ceil_div(rows, 32) * taps * ceil_div(kch, 16) * 512;
 }
 
+static int pack_weights_impl(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int taps_kk, void* stream);
 extern "C" int oct_pack_weights(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, void* stream) {
+  return pack_weights_impl(mode, dtype, w, wpacked, cout, cin, 0, stream);
+}
+extern "C" int oct_pack_weights_kk(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int kh, int kw,
+                                   void* stream) {
+  OCT_CHECK(mode == OCT_PACK_CONV_FPROP || mode == OCT_PACK_CONV_DGRAD, "oct_pack_weights_kk: mode must be CONV_FPROP or CONV_DGRAD");
+  OCT_CHECK(kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && kh * kw <= 49, "oct_pack_weights_kk: odd kernel sizes up to 7x7 (got %dx%d)", kh, kw);
+  return pack_weights_impl(mode, dtype, w, wpacked, cout, cin, kh * kw, stream);
+}
+static int pack_weights_impl(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int taps_kk, void* stream) {
   OCT_CHECK(mode >= 0 && mode <= 5, "oct_pack_weights: bad mode %d", mode);
   OCT_CHECK(cout > 0 && cin > 0 && w && wpacked, "oct_pack_weights: bad arguments");
   int rows, taps, kch;
   pack_dims(mode, cout, cin, &rows, &taps, &kch);
+  if (taps_kk > 0) taps = taps_kk;
   const int nk16 = ceil_div(kch, 16);
   const size_t total = oct_packed_weight_elems(rows, taps, kch);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -412,33 +431,59 @@ static TileCfg pick_cfg(int cout) {
 
 extern "C" int oct_conv_stat_blocks(const OctConvDesc* d) {
   if (!d) return 0;
-  const int f1 = oct_first_stat_rows(d);
-  if (f1 >= 0) return f1;
-  const int v3 = oct_conv_v3_stat_rows(d);
-  if (v3 >= 0) return v3;
-  const int v2 = oct_conv_v2_stat_rows(d);
-  if (v2 >= 0) return v2;
+  if (d->kh != 7) {
+    const int f1 = oct_first_stat_rows(d);
+    if (f1 >= 0) return f1;
+    const int v2 = oct_conv_v2_stat_rows(d);
+    if (v2 >= 0) return v2;
+  }
   const TileCfg c = pick_cfg(d->cout);
   return ceil_div(d->w, 32) * ceil_div(d->h, c.th) * d->n;
 }
 
-template <typename T, int TAPS>
+template <typename T, int KH, int KW, int WM, int WN, int MF, int NF>
+static void launch_igemm_cfg(const IgemmParams& p, dim3 grid, hipStream_t s) {
+  constexpr int TH = WM * MF, NT = WN * NF * 32, PIXB = 32 * (int)sizeof(T) + 16;
+  constexpr int lds = (TH + KH - 1) * (32 + KW - 1) * PIXB + WM * 2 * NT * (int)sizeof(float);
+  if (lds > 64 * 1024) {   // 7x3 in fp32: 14 x 34 pixels x 144 B
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, KH, KW, WM, WN, MF, NF, 32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = true;
+    }
+  }
+  hipLaunchKernelGGL((igemm_kernel<T, KH, KW, WM, WN, MF, NF, 32>), grid, dim3(256), lds, s, p);
+}
+template <typename T, int KH, int KW>
 static int launch_igemm(const OctConvDesc* d, const IgemmParams& p, hipStream_t s) {
   const TileCfg c = pick_cfg(d->cout);
   dim3 grid(p.tiles_x * p.tiles_y * p.n, ceil_div(d->cout, c.nt));
-  if (c.nt == 32)
-    hipLaunchKernelGGL((igemm_kernel<T, TAPS, 4, 1, 2, 1, 32>), grid, dim3(256), 0, s, p);
-  else if (c.nt == 64)
-    hipLaunchKernelGGL((igemm_kernel<T, TAPS, 2, 2, 4, 1, 32>), grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((igemm_kernel<T, TAPS, 2, 2, 4, 2, 32>), grid, dim3(256), 0, s, p);
+  if (c.nt == 32) launch_igemm_cfg<T, KH, KW, 4, 1, 2, 1>(p, grid, s);
+  else if (c.nt == 64) launch_igemm_cfg<T, KH, KW, 2, 2, 4, 1>(p, grid, s);
+  else launch_igemm_cfg<T, KH, KW, 2, 2, 4, 2>(p, grid, s);
   return oct_check_launch("igemm");
+}
+
+// kernel size of a descriptor: kh = kw = 0 means "from taps" (9 -> 3x3, 1 -> 1x1), as before the fields existed
+bool oct_conv_kernel_size(int taps, int kh_in, int kw_in, int* kh, int* kw) {
+  if (kh_in == 0 && kw_in == 0) {
+    if (taps == 9) { *kh = 3; *kw = 3; return true; }
+    if (taps == 1) { *kh = 1; *kw = 1; return true; }
+    return false;
+  }
+  *kh = kh_in; *kw = kw_in;
+  return taps == kh_in * kw_in && ((kh_in == 3 && kw_in == 3) || (kh_in == 1 && kw_in == 1) || (kh_in == 7 && kw_in == 3));
 }
 
 extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
   OCT_CHECK(d && a, "oct_conv_forward: null descriptor");
   OCT_CHECK(d->dtype == OCT_DT_BF16 || d->dtype == OCT_DT_F32, "oct_conv_forward: bad dtype %d", d->dtype);
-  OCT_CHECK(d->taps == 9 || d->taps == 1, "oct_conv_forward: taps must be 9 or 1 (got %d)", d->taps);
+  int kh = 0, kw = 0;
+  OCT_CHECK(oct_conv_kernel_size(d->taps, d->kh, d->kw, &kh, &kw),
+            "oct_conv_forward: kernel must be 3x3 (taps 9), 1x1 (taps 1) or 7x3 (taps 21, kh=7, kw=3); got taps=%d kh=%d kw=%d",
+            d->taps, d->kh, d->kw);
+  OCT_CHECK(kh != 7 || (d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN), "oct_conv_forward: 7x3 runs plain -> plain");
   OCT_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->c0 > 0 && d->c1 >= 0 && d->cout > 0,
             "oct_conv_forward: bad shape n=%d h=%d w=%d c0=%d c1=%d cout=%d", d->n, d->h, d->w, d->c0, d->c1, d->cout);
   OCT_CHECK(a->x0 && a->wpacked && a->y0, "oct_conv_forward: null tensor");
@@ -451,9 +496,8 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_forward: xform1 without scale/shift");
   OCT_CHECK(!(d->want_stats && !a->stat_partials), "oct_conv_forward: want_stats without buffer");
   OCT_CHECK((size_t)d->n * d->h * d->w < (1u << 31), "oct_conv_forward: too many pixels");
-  {
+  if (kh != 7) {
     int took = oct_first_fprop(d, a, stream);
-    if (took == 0) took = oct_conv_forward_v3(d, a, stream);
     if (took == 0) took = oct_conv_forward_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
   }
@@ -470,6 +514,6 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
   p.tiles_x = ceil_div(d->w, 32); p.tiles_y = ceil_div(d->h, c.th);
   hipStream_t s = as_stream(stream);
   if (d->dtype == OCT_DT_BF16)
-    return d->taps == 9 ? launch_igemm<bf16_t, 9>(d, p, s) : launch_igemm<bf16_t, 1>(d, p, s);
-  return d->taps == 9 ? launch_igemm<float, 9>(d, p, s) : launch_igemm<float, 1>(d, p, s);
+    return kh == 7 ? launch_igemm<bf16_t, 7, 3>(d, p, s) : kh == 3 ? launch_igemm<bf16_t, 3, 3>(d, p, s) : launch_igemm<bf16_t, 1, 1>(d, p, s);
+  return kh == 7 ? launch_igemm<float, 7, 3>(d, p, s) : kh == 3 ? launch_igemm<float, 3, 3>(d, p, s) : launch_igemm<float, 1, 1>(d, p, s);
 }

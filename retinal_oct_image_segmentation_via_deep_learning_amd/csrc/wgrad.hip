@@ -20,6 +20,7 @@ struct WgradParams {
   int cout;            // GEMM rows (4*Cout for the deconv)
   int xf0, xf1, dy_mode;
   int tiles_x, tiles_y, ntiles;
+  int ty0, pad_h, pad_w;   // first kernel row this launch covers, "same" padding of the whole kernel
 };
 
 template <typename T>
@@ -90,11 +91,14 @@ __device__ __forceinline__ void wg_fetch_dy8(const WgradParams& p, int img, int 
   }
 }
 
-template <typename T, int TAPS>
+// One launch covers TR consecutive kernel rows (all KW columns) starting at row p.ty0: 3x3 = one launch of
+// <3,3>, 1x1 / deconv = <1,1>, ReLayNet's 7x3 = rows {0-2}, {3-5}, {6} -- the register budget (16 accumulators
+// per tap) caps a launch at 9 taps.  Input rows are staged with the matching vertical offset.
+template <typename T, int TR, int KW>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+  constexpr int TAPS = TR * KW;
   constexpr int TH = 8, TW = 32;
-  constexpr int HALO = (TAPS == 9) ? 1 : 0;
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr int LH = TH + TR - 1, LW = TW + KW - 1;
   constexpr int PIXE = 32 + 8 / (int)sizeof(T) * 2;  // elements per LDS pixel: 32 channels + pad (keeps 16-B rows)
   typedef Mma<T> M;
   typedef typename M::Frag Frag;
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     for (int idx = tid; idx < LH * LW * 4; idx += 256) {
       const int pix = idx >> 2, grp = idx & 3;
       const int ly = pix / LW, lx = pix - ly * LW;
-      const int iy = y0 + ly - HALO, ix = x0 + lx - HALO;
+      const int iy = y0 + ly + p.ty0 - p.pad_h, ix = x0 + lx - p.pad_w;
       float v[8];
       if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
         wg_fetch_in8<T>(p, ((size_t)img * p.h + iy) * (size_t)p.w + ix, ci0 + grp * 8, v);
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       }
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
-        const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
+        const int ty = t / KW, tx = t % KW;
         Frag b = M::zero();
 #pragma unroll
         for (int j = 0; j < 8; ++j) M::set(b, j, in_tile[((row + ty) * LW + xs + j + tx) * PIXE + r]);
@@ -181,7 +185,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (co < p.cout) atomicAdd(&p.dwp[((size_t)t * p.cout + co) * p.ktot + ci], acc[t][i]);
+        if (co < p.cout) atomicAdd(&p.dwp[((size_t)(p.ty0 * KW + t) * p.cout + co) * p.ktot + ci], acc[t][i]);
       }
   }
 }
@@ -189,14 +193,18 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
   OCT_CHECK(d && a, "oct_conv_wgrad: null descriptor");
   OCT_CHECK(d->dtype == OCT_DT_BF16 || d->dtype == OCT_DT_F32, "oct_conv_wgrad: bad dtype %d", d->dtype);
-  OCT_CHECK(d->taps == 9 || d->taps == 1, "oct_conv_wgrad: taps must be 9 or 1");
+  int kh = 0, kw = 0;
+  OCT_CHECK(oct_conv_kernel_size(d->taps, d->kh, d->kw, &kh, &kw),
+            "oct_conv_wgrad: kernel must be 3x3 (taps 9), 1x1 (taps 1) or 7x3 (taps 21, kh=7, kw=3); got taps=%d kh=%d kw=%d",
+            d->taps, d->kh, d->kw);
+  OCT_CHECK(kh != 7 || (d->dy_mode == OCT_IN_PLAIN && !a->dy_coef), "oct_conv_wgrad: 7x3 takes a plain dY");
   OCT_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->c0 > 0 && d->c1 >= 0 && d->cout > 0, "oct_conv_wgrad: bad shape");
   OCT_CHECK(a->x0 && a->dy && a->dwp, "oct_conv_wgrad: null tensor");
   OCT_CHECK(d->c1 == 0 || a->x1, "oct_conv_wgrad: c1 > 0 but x1 is null");
   OCT_CHECK(!(d->dy_mode == OCT_IN_S2D && (d->cout & 3)), "oct_conv_wgrad: S2D dy needs cout %% 4 == 0");
   OCT_CHECK(!(d->xform0 && (!a->scale0 || !a->shift0)), "oct_conv_wgrad: xform0 without scale/shift");
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
-  {
+  if (kh != 7) {
     int took = oct_first_wgrad(d, a, stream);
     if (took == 0 && a->dy_coef) OCT_CHECK(false, "oct_conv_wgrad: the fused BN-backward apply is only implemented for the 1->F first layer in bf16");
     if (took == 0) took = oct_conv_wgrad_v2(d, a, stream);
@@ -214,36 +222,44 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   if (per_pair < 1) per_pair = 1;
   if (per_pair > p.ntiles) per_pair = p.ntiles;
   dim3 grid(per_pair, nco, nci);
-  const int halo = d->taps == 9 ? 1 : 0;
   const int esz = d->dtype == OCT_DT_BF16 ? 2 : 4;
   const int pixe = 32 + 8 / esz * 2;
-  const size_t lds = (size_t)((8 + 2 * halo) * (32 + 2 * halo) + 8 * 32) * pixe * esz;
+  p.pad_h = (kh - 1) / 2; p.pad_w = (kw - 1) / 2;
   hipStream_t s = as_stream(stream);
-  if (d->dtype == OCT_DT_BF16) {
-    if (d->taps == 9) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 9>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1>), grid, dim3(256), lds, s, p);
-  } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, 9>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-      attr_set = true;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    attr_set = true;
+  }
+  const bool bf = d->dtype == OCT_DT_BF16;
+  for (int ty0 = 0; ty0 < kh; ty0 += 3) {
+    const int tr = kh - ty0 >= 3 ? 3 : 1;           // kh in {1, 3, 7}: groups of three rows, then single rows
+    p.ty0 = ty0;
+    if (ty0 > 0) p.dbias = nullptr;                  // the bias gradient belongs to one launch only
+    const size_t lds = (size_t)((8 + tr - 1) * (32 + kw - 1) + 8 * 32) * pixe * esz;
+    if (tr == 3 && kw == 3) {
+      if (bf) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3, 3>), grid, dim3(256), lds, s, p);
+      else hipLaunchKernelGGL((wgrad_kernel<float, 3, 3>), grid, dim3(256), lds, s, p);
+    } else if (tr == 1 && kw == 3) {
+      if (bf) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 3>), grid, dim3(256), lds, s, p);
+      else hipLaunchKernelGGL((wgrad_kernel<float, 1, 3>), grid, dim3(256), lds, s, p);
+    } else {
+      if (bf) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 1>), grid, dim3(256), lds, s, p);
+      else hipLaunchKernelGGL((wgrad_kernel<float, 1, 1>), grid, dim3(256), lds, s, p);
     }
-    if (d->taps == 9) hipLaunchKernelGGL((wgrad_kernel<float, 9>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<float, 1>), grid, dim3(256), lds, s, p);
   }
   return oct_check_launch("wgrad");
 }
 
 // dwp[tap][rows][kch] -> torch-layout gradient
 __global__ void unpack_wgrad_kernel(int mode, const float* __restrict__ dwp, float* __restrict__ grad, int cout,
-                                    int cin, int accumulate, size_t total) {
+                                    int cin, int accumulate, size_t total, int taps) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float v;
     if (mode == OCT_PACK_CONV_FPROP) {  // grad[co][ci][tap]
-      const int tap = i % 9; const size_t r = i / 9; const int ci = r % cin; const int co = r / cin;
+      const int tap = i % taps; const size_t r = i / taps; const int ci = r % cin; const int co = r / cin;
       v = dwp[((size_t)tap * cout + co) * cin + ci];
     } else if (mode == OCT_PACK_DECONV_FPROP) {  // grad[ci][co][dydx] ; dwp[0][dydx*cout+co][ci]
       const int dydx = i & 3; const size_t r = i >> 2; const int co = r % cout; const int ci = r / cout;
@@ -301,6 +317,17 @@ extern "C" int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cou
   const size_t total = (size_t)cout * cin * (mode == OCT_PACK_CONV_FPROP ? 9 : mode == OCT_PACK_DECONV_FPROP ? 4 : 1);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), mode, dwp, grad, cout, cin,
-                     accumulate, total);
+                     accumulate, total, 9);
   return oct_check_launch("unpack_wgrad");
+}
+
+// dwp[kh*kw][cout][cin] -> grad (Cout, Cin, kh, kw) for any kernel size (ReLayNet's 7x3)
+extern "C" int oct_unpack_wgrad_kk(const float* dwp, float* grad, int cout, int cin, int kh, int kw, int accumulate,
+                                   void* stream) {
+  OCT_CHECK(dwp && grad && cout > 0 && cin > 0 && kh > 0 && kw > 0, "oct_unpack_wgrad_kk: bad arguments");
+  const size_t total = (size_t)cout * cin * kh * kw;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), OCT_PACK_CONV_FPROP, dwp, grad,
+                     cout, cin, accumulate, total, kh * kw);
+  return oct_check_launch("unpack_wgrad_kk");
 }

@@ -225,11 +225,12 @@ class UNetEngine:
             self._packed.update(news)
 
     def _conv(self, src: Src, wpacked, cout, taps, n, h, w, y0, *, y1=None, split=0, in_mode=L.IN_PLAIN,
-              out_mode=L.OUT_PLAIN, bias=None, stats=None):
+              out_mode=L.OUT_PLAIN, bias=None, stats=None, kh=0, kw=0):
+        """taps 9 / 1 = 3x3 / 1x1; any other kernel passes (kh, kw) and taps = kh*kw (7x3: ReLayNet)."""
         d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                        L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE,
-                       in_mode, out_mode, split, 1 if stats is not None else 0)
+                       in_mode, out_mode, split, 1 if stats is not None else 0, kh, kw)
         a = L.ConvArgs(L.ptr(src.x0), L.ptr(src.x1),
                        L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                        L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
@@ -238,20 +239,20 @@ class UNetEngine:
         L.check(L.lib().oct_conv_forward(C.byref(d), C.byref(a), _stream()), "oct_conv_forward")
         self._prof_end(ev, "igemm")
 
-    def _stat_blocks(self, cout, n, h, w, src: Src, taps=9):
+    def _stat_blocks(self, cout, n, h, w, src: Src, taps=9, kh=0, kw=0):
         """rows of the partial-statistics buffer the conv with this exact descriptor will write"""
         d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                        L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
-                       L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, 0, 0, 0, 1)
+                       L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, 0, 0, 0, 1, kh, kw)
         return L.lib().oct_conv_stat_blocks(C.byref(d))
 
-    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None, fused_apply=None):
+    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None, fused_apply=None, kh=0, kw=0):
         """fused_apply = (y, coef, scale, shift): `dy` holds dA and the kernel applies BN backward on load."""
         ktot = src.channels
         dwp = self._dwp_take(taps * cout * ktot, dy.device).view(taps, cout, ktot)
         d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                         L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
-                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, dy_mode)
+                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, dy_mode, kh, kw)
         a = L.WgradArgs(L.ptr(src.x0), L.ptr(src.x1),
                         L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                         L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,

@@ -35,7 +35,7 @@ _PACK_SHAPE = {
     L.PACK_1X1_DGRAD: lambda co, ci: (ci, 1, co), L.PACK_1X1_FPROP: lambda co, ci: (co, 1, ci)}
 
 
-def packed(e: UNetEngine, w: torch.Tensor, mode: int, cout: int, cin: int, cache: bool = True) -> torch.Tensor:
+def packed(e: UNetEngine, w: torch.Tensor, mode: int, cout: int, cin: int, cache: bool = True, kk=None) -> torch.Tensor:
     """MFMA-fragment-ordered copy of a weight in the compute dtype.  The copy lives on the
     parameter object itself (so it dies with it and can never be mistaken for another tensor that
     later reuses the address) and is refreshed when torch's version counter or the raw-pointer
@@ -47,8 +47,14 @@ def packed(e: UNetEngine, w: torch.Tensor, mode: int, cout: int, cin: int, cache
     if hit is not None and hit[0] == ver:
         return hit[1]
     rows, taps, kch = _PACK_SHAPE[mode](cout, cin)
+    if kk is not None:      # general kernel size (7x3): same modes, taps = kh*kw
+        taps = kk[0] * kk[1]
     out = torch.empty(L.lib().oct_packed_weight_elems(rows, taps, kch), dtype=e.tdt, device=w.device)
-    L.check(L.lib().oct_pack_weights(mode, e.dt, w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "oct_pack_weights")
+    if kk is not None:
+        L.check(L.lib().oct_pack_weights_kk(mode, e.dt, w.data_ptr(), out.data_ptr(), cout, cin, kk[0], kk[1], _stream()),
+                "oct_pack_weights_kk")
+    else:
+        L.check(L.lib().oct_pack_weights(mode, e.dt, w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "oct_pack_weights")
     store[slot] = (ver, out)
     return out
 
@@ -97,13 +103,14 @@ class ToNCHW(torch.autograd.Function):
 
 class ConvAffineAct(torch.autograd.Function):
     """out = act(affine(conv(cat(x0, x1), w)) (+ res)) with affine = train/eval BatchNorm (bn given) or
-    `+ bias` (bn None).  3x3 pad 1 or 1x1, chosen by the weight's shape.
+    `+ bias` (bn None).  3x3 pad 1, 1x1 or 7x3 pad (3,1) (ReLayNet_2017.py:155-160), chosen by the weight's shape.
+    act = ACT_PRELU takes `alpha` (nn.PReLU's single slope) and returns its gradient.
 
     bn: the nn.BatchNorm2d container (running buffers are updated in train mode, momentum 0.1).
     A conv bias in front of a train-mode BN only moves the running mean; its gradient is zero."""
 
     @staticmethod
-    def forward(ctx, dtype, bn, act, x0, x1, w, cbias, gamma, beta, res):
+    def forward(ctx, dtype, bn, act, x0, x1, w, cbias, gamma, beta, res, alpha=None):
         e = kernels(dtype)
         lib = L.lib()
         x0 = x0.contiguous()
@@ -112,22 +119,27 @@ class ConvAffineAct(torch.autograd.Function):
         if x1 is not None:
             x1 = x1.contiguous()
             c1 = x1.shape[3]
-        cout, cin, kh, _ = w.shape
-        if cin != c0 + c1 or kh not in (1, 3):
-            raise RuntimeError(f"conv weight {tuple(w.shape)} does not fit an input with {c0 + c1} channels")
-        taps = 9 if kh == 3 else 1
+        cout, cin, kh, kw = w.shape
+        if cin != c0 + c1 or (kh, kw) not in ((1, 1), (3, 3), (7, 3)):
+            raise RuntimeError(f"conv weight {tuple(w.shape)} does not fit an input with {c0 + c1} channels "
+                               f"/ a 1x1, 3x3 or 7x3 kernel")
+        taps = kh * kw
+        kk = (kh, kw) if taps == 21 else None
+        kd = dict(kh=kh, kw=kw) if kk else {}
+        if act == L.ACT_PRELU and (alpha is None or res is not None):
+            raise RuntimeError("PReLU needs its slope parameter (and takes no residual)")
         dev = x0.device
         src = Src(x0, c0, None, x1, c1, None)
-        wp = packed(e, w, L.PACK_CONV_FPROP if taps == 9 else L.PACK_1X1_FPROP, cout, cin)
+        wp = packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
         y = e._act(n, h, wd, cout, dev)
         scale = torch.empty(cout, dtype=torch.float32, device=dev)
         shift = torch.empty_like(scale)
         mean = invstd = None
         train_bn = bn is not None and bn.training
         if train_bn:
-            nblk = e._stat_blocks(cout, n, h, wd, src, taps)
+            nblk = e._stat_blocks(cout, n, h, wd, src, taps, **kd)
             partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
-            e._conv(src, wp, cout, taps, n, h, wd, y, stats=partials)
+            e._conv(src, wp, cout, taps, n, h, wd, y, stats=partials, **kd)
             mean, invstd = torch.empty_like(scale), torch.empty_like(scale)
             L.check(lib.oct_bn_finalize(partials.data_ptr(), nblk, cout, float(n * h * wd), gamma.data_ptr(),
                                         beta.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(),
@@ -135,7 +147,7 @@ class ConvAffineAct(torch.autograd.Function):
                                         scale.data_ptr(), shift.data_ptr(), L.ptr(cbias), _stream()), "oct_bn_finalize")
             bn.num_batches_tracked.add_(1)
         else:
-            e._conv(src, wp, cout, taps, n, h, wd, y)
+            e._conv(src, wp, cout, taps, n, h, wd, y, **kd)
             if bn is not None:
                 L.check(lib.oct_bn_eval_coeffs(cout, gamma.data_ptr(), beta.data_ptr(),
                                                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_EPS,
@@ -150,16 +162,22 @@ class ConvAffineAct(torch.autograd.Function):
         out = e._act(n, h, wd, cout, dev)
         if res is not None:
             res = res.contiguous()
-        L.check(lib.oct_affine_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), act,
-                                       out.data_ptr(), n * h * wd, cout, _stream()), "oct_affine_act_fwd")
-        ctx.cfg = (dtype, bn, act, taps, train_bn, res is not None, cbias is not None)
-        ctx.save_for_backward(x0, x1, w, y, out, mean, invstd, scale, gamma)
+        if act == L.ACT_PRELU:
+            L.check(lib.oct_affine_prelu_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), alpha.data_ptr(),
+                                             out.data_ptr(), n * h * wd, cout, _stream()), "oct_affine_prelu_fwd")
+        else:
+            L.check(lib.oct_affine_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), act,
+                                           out.data_ptr(), n * h * wd, cout, _stream()), "oct_affine_act_fwd")
+        ctx.cfg = (dtype, bn, act, taps, train_bn, res is not None, cbias is not None, kk)
+        ctx.save_for_backward(x0, x1, w, y, out, mean, invstd, scale, gamma, shift, alpha)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        dtype, bn, act, taps, train_bn, has_res, has_bias = ctx.cfg
-        x0, x1, w, y, out, mean, invstd, scale, gamma = ctx.saved_tensors
+        dtype, bn, act, taps, train_bn, has_res, has_bias, kk = ctx.cfg
+        x0, x1, w, y, out, mean, invstd, scale, gamma, shift, alpha = ctx.saved_tensors
+        kd = dict(kh=kk[0], kw=kk[1]) if kk else {}
+        dalpha = None
         e = kernels(dtype)
         lib = L.lib()
         n, h, wd, c0 = x0.shape
@@ -170,7 +188,14 @@ class ConvAffineAct(torch.autograd.Function):
         dout = dout.contiguous()
         if bn is not None and not train_bn:
             raise NotImplementedError("backward through an eval-mode BatchNorm is not on the HIP path")
-        if act != L.ACT_NONE:
+        if act == L.ACT_PRELU:
+            dz = torch.empty_like(dout)
+            dalpha = torch.zeros(1, dtype=torch.float32, device=dev)
+            L.check(lib.oct_affine_prelu_bwd(e.dt, dout.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                             alpha.data_ptr(), dz.data_ptr(), dalpha.data_ptr(), npix, cout, _stream()),
+                    "oct_affine_prelu_bwd")
+            dalpha = dalpha.reshape(alpha.shape)
+        elif act != L.ACT_NONE:
             dz = torch.empty_like(dout)
             L.check(lib.oct_act_bwd(e.dt, dout.data_ptr(), out.data_ptr(), act, dz.data_ptr(), dz.numel(), _stream()),
                     "oct_act_bwd")
@@ -203,16 +228,20 @@ class ConvAffineAct(torch.autograd.Function):
                 L.check(lib.oct_channel_sum(e.dt, dy.data_ptr(), dcb.data_ptr(), npix, cout, 0, _stream()),
                         "oct_channel_sum")
         src = Src(x0, c0, None, x1, c1, None)
-        dwp = e._wgrad(src, dy, cout, taps, n, h, wd)
+        dwp = e._wgrad(src, dy, cout, taps, n, h, wd, **kd)
         dw = torch.empty_like(w)
-        e._unpack(L.PACK_CONV_FPROP if taps == 9 else L.PACK_1X1_FPROP, dwp, dw, cout, cin, False)
+        if kk:
+            L.check(lib.oct_unpack_wgrad_kk(dwp.data_ptr(), dw.data_ptr(), cout, cin, kk[0], kk[1], 0, _stream()),
+                    "oct_unpack_wgrad_kk")
+        else:
+            e._unpack(L.PACK_CONV_FPROP if taps == 9 else L.PACK_1X1_FPROP, dwp, dw, cout, cin, False)
         d0 = d1 = None
         if ctx.needs_input_grad[3] or (x1 is not None and ctx.needs_input_grad[4]):  # x0 / x1
-            wp = packed(e, w, L.PACK_CONV_DGRAD if taps == 9 else L.PACK_1X1_DGRAD, cout, cin)
+            wp = packed(e, w, L.PACK_1X1_DGRAD if taps == 1 else L.PACK_CONV_DGRAD, cout, cin, kk=kk)
             d0 = e._act(n, h, wd, c0, dev)
             d1 = e._act(n, h, wd, c1, dev) if c1 else None
-            e._conv(Src(dy, cout), wp, cin, taps, n, h, wd, d0, y1=d1, split=c0 if c1 else 0)
-        return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres
+            e._conv(Src(dy, cout), wp, cin, taps, n, h, wd, d0, y1=d1, split=c0 if c1 else 0, **kd)
+        return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres, dalpha
 
 
 class MaxPool(torch.autograd.Function):
@@ -240,6 +269,68 @@ class MaxPool(torch.autograd.Function):
         L.check(L.lib().oct_maxpool_bwd(e.dt, a.data_ptr(), dout.data_ptr(), da.data_ptr(), n, h, w, c, k, _stream()),
                 "oct_maxpool_bwd")
         return None, None, da
+
+
+class MaxPoolIdx(torch.autograd.Function):
+    """nn.MaxPool2d(k, k, return_indices=True) on NHWC: (pooled, idx) with torch's per-plane index iy*W + ix.
+    Backward = scatter of the pooled gradient to the recorded winners."""
+
+    @staticmethod
+    def forward(ctx, dtype, k, a):
+        e = kernels(dtype)
+        a = a.contiguous()
+        n, h, w, c = a.shape
+        if h % k or w % k:
+            raise RuntimeError(f"max-pool window {k} does not divide {h}x{w}")
+        out = e._act(n, h // k, w // k, c, a.device)
+        idx = torch.empty((n, h // k, w // k, c), dtype=torch.int64, device=a.device)
+        L.check(L.lib().oct_maxpool_idx_fwd(e.dt, a.data_ptr(), out.data_ptr(), idx.data_ptr(), n, h, w, c, k, _stream()),
+                "oct_maxpool_idx_fwd")
+        ctx.cfg = (dtype, (n, h, w, c))
+        ctx.save_for_backward(idx)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, dout, _didx):
+        dtype, (n, h, w, c) = ctx.cfg
+        (idx,) = ctx.saved_tensors
+        e = kernels(dtype)
+        dout = dout.contiguous()
+        da = torch.zeros((n, h, w, c), dtype=e.tdt, device=dout.device)
+        L.check(L.lib().oct_index_scatter(e.dt, dout.data_ptr(), idx.data_ptr(), da.data_ptr(), n, idx.shape[1] * idx.shape[2],
+                                          h * w, c, _stream()), "oct_index_scatter")
+        return None, None, da
+
+
+class MaxUnpool(torch.autograd.Function):
+    """nn.MaxUnpool2d(k, k) on NHWC: v (n,hp,wp,c) scattered to (n, hp*k, wp*k, c) at idx; backward = gather."""
+
+    @staticmethod
+    def forward(ctx, dtype, k, v, idx):
+        e = kernels(dtype)
+        v, idx = v.contiguous(), idx.contiguous()
+        n, hp, wp, c = v.shape
+        if idx.shape != v.shape or idx.dtype != torch.int64:
+            raise RuntimeError(f"indices must be int64 of the pooled shape {tuple(v.shape)}, got {idx.dtype} {tuple(idx.shape)}")
+        out = torch.zeros((n, hp * k, wp * k, c), dtype=e.tdt, device=v.device)
+        L.check(L.lib().oct_index_scatter(e.dt, v.data_ptr(), idx.data_ptr(), out.data_ptr(), n, hp * wp, hp * k * wp * k, c,
+                                          _stream()), "oct_index_scatter")
+        ctx.cfg = (dtype, k)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dtype, k = ctx.cfg
+        (idx,) = ctx.saved_tensors
+        e = kernels(dtype)
+        dout = dout.contiguous()
+        n, hp, wp, c = idx.shape
+        dv = e._act(n, hp, wp, c, dout.device)
+        L.check(L.lib().oct_index_gather(e.dt, dout.data_ptr(), idx.data_ptr(), dv.data_ptr(), n, hp * wp, hp * k * wp * k, c,
+                                         _stream()), "oct_index_gather")
+        return None, None, dv, None
 
 
 class BilinearUp(torch.autograd.Function):
@@ -362,10 +453,16 @@ class Gate(torch.autograd.Function):
 
 
 # ---- functional spellings -----------------------------------------------------------------------
-def conv_bn_act(dtype, x0, conv, bn=None, act=L.ACT_NONE, x1=None, res=None):
-    """conv: nn.Conv2d container (3x3 pad 1 or 1x1); bn: nn.BatchNorm2d container or None."""
+def conv_bn_act(dtype, x0, conv, bn=None, act=L.ACT_NONE, x1=None, res=None, prelu=None):
+    """conv: nn.Conv2d container (3x3 pad 1, 1x1, or 7x3 pad (3,1)); bn: nn.BatchNorm2d container or None;
+    prelu: nn.PReLU container (num_parameters 1) -> act becomes PReLU."""
+    if prelu is not None:
+        if prelu.weight.numel() != 1:
+            raise NotImplementedError("per-channel PReLU is not on the HIP path (the reference uses nn.PReLU())")
+        act = L.ACT_PRELU
     return ConvAffineAct.apply(dtype, bn, act, x0, x1, conv.weight, conv.bias,
-                               bn.weight if bn is not None else None, bn.bias if bn is not None else None, res)
+                               bn.weight if bn is not None else None, bn.bias if bn is not None else None, res,
+                               prelu.weight if prelu is not None else None)
 
 
 def to_nhwc(x, dtype):

@@ -77,7 +77,7 @@ CONV_SHAPES = [
     (1, 16, 32, 64, 0, 128),
     (1, 8, 32, 128, 128, 256), # two channel blocks of 128, concat
     (3, 8, 32, 96, 0, 192),    # Cout multiple of 64 only
-    # Cout % 128 == 0, H % 16 == 0 -> cooperative 8-wave kernel (igemm3.hip)
+    # Cout % 128 == 0, H % 16 == 0
     (2, 32, 64, 64, 64, 128),  # several tiles per image, concat, dgrad splits 64/64
     (1, 16, 64, 128, 0, 256),  # two channel blocks
     (3, 16, 32, 32, 0, 128),   # two stages per item only
@@ -419,17 +419,3 @@ def test_errors_are_reported_not_thrown(env):
     assert rc == -22 and "taps" in L.last_error()
     with pytest.raises(L.OctError):
         L.check(rc, "oct_conv_forward")
-
-
-def test_cooperative_igemm3_opt_in_matches_oracle():
-    """igemm3.hip (8 MFMA waves per workgroup, weights through LDS-DMA) is opt-in (OCT_ENABLE_V3=1, read
-    once per process): run the conv tests of its eligible shapes in a child process with the switch on."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, OCT_ENABLE_V3="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
-                        "-k", "conv3x3 and bf16 and (shape3 or shape14 or shape17 or shape18 or shape19 or shape20)"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]

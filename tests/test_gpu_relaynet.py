@@ -1,0 +1,162 @@
+"""GPU parity of the ReLayNet drop-ins against the fixtures produced by the reference's own
+classes (tools/gen_golden_relaynet.py): 7x3 implicit-GEMM convolution (fprop, dgrad, wgrad in three row groups),
+BatchNorm + PReLU (with the slope's gradient), MaxPool2d with indices, MaxUnpool2d, cat((skip, unpooled)).
+fp32 parity mode: outputs 2e-5 of their scale, gradients 2e-3 of the tensor's max, pooling indices identical;
+bf16 production mode: against the same fixtures with bf16-sized bounds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_oracle_relaynet import NETS, block_io
+
+pytestmark = pytest.mark.gpu
+
+P = {"num_channels": 3, "num_filters": 8, "kernel_h": 7, "kernel_w": 3, "stride_conv": 1, "pool": 2, "stride_pool": 2,
+     "kernel_c": 1}
+
+
+def dropin(name, dtype):
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Lesions_Segment import ReLayNet_2017 as R
+    return {"relay_basic": lambda: R.BasicBlock(dict(P), dtype), "relay_encoder": lambda: R.EncoderBlock(dict(P), dtype),
+            "relay_decoder": lambda: R.DecoderBlock(dict(P, num_channels=16), dtype),
+            "relay_classifier": lambda: R.ClassifierBlock(dict(P, num_channels=8, num_class=5), dtype)}[name]()
+
+
+def close(got, ref, key, rel, floor=1e-4):
+    ref = np.asarray(ref, np.float64)
+    tol = rel * max(float(np.abs(ref).max()), floor)
+    err = float(np.abs(np.asarray(got, np.float64) - ref).max())
+    assert err <= tol, f"{key}: max err {err:.3e} > {tol:.3e}"
+
+
+@pytest.mark.parametrize("name", ["relay_basic", "relay_encoder", "relay_decoder", "relay_classifier"])
+def test_f32_block_matches_reference_fixture(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = dropin(name, "f32")
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}, strict=True)
+    m.cuda().train()
+    xs, extra = block_io(z)
+    xd = [x.cuda().requires_grad_(True) for x in xs]
+    out = m(*xd, *[e.cuda() for e in extra])
+    outs = out if isinstance(out, tuple) else (out,)
+    assert len(outs) == int(z["n_out"])
+    loss = 0
+    for i, o in enumerate(outs):
+        if o.dtype.is_floating_point:
+            close(o.detach().cpu().numpy(), z[f"out{i}"], f"out{i}", 2e-5, 1.0)
+            loss = loss + (o * torch.from_numpy(z[f"r{i}"]).cuda()).sum()
+        else:
+            assert o.dtype == torch.int64 and np.array_equal(o.cpu().numpy(), z[f"out{i}"]), "pooling indices"
+    loss.backward()
+    for i, x in enumerate(xd):
+        close(x.grad.cpu().numpy(), z[f"gx{i}"], f"gx{i}", 2e-3)
+    for k, p in m.named_parameters():
+        close(p.grad.cpu().numpy(), z["g/" + k], k, 2e-3)
+    sd = m.state_dict()
+    for k in z.files:
+        if k.startswith("b1/"):
+            if "num_batches" in k:
+                assert int(sd[k[3:]]) == int(z[k])
+            else:
+                close(sd[k[3:]].cpu().numpy(), z[k], k, 1e-4)
+    m.eval()
+    with torch.no_grad():
+        oe = m(*[x.cuda() for x in xs], *[e.cuda() for e in extra])
+        close((oe[0] if isinstance(oe, tuple) else oe).cpu().numpy(), z["out_eval"], "out_eval", 2e-5, 1.0)
+
+
+def load_net(golden_dir, name, dtype):
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Lesions_Segment.ReLayNet_2017 import ReLayNet
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    seed, n, cin, ncls, nf, h, w = (int(v) for v in z["meta"])
+    m = ReLayNet(in_channels=cin, num_classes=ncls, num_filters=nf, compute_dtype=dtype)
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}, strict=True)
+    return z, m.cuda().train()
+
+
+@pytest.mark.parametrize("name", NETS)
+def test_f32_network_matches_reference_fixture(golden_dir, name):
+    z, m = load_net(golden_dir, name, "f32")
+    x, t = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["target"]).cuda()
+    out = m(x)
+    lg = out.detach().cpu().numpy()
+    close(lg, z["logits"], "logits", 2e-5, 1.0)
+    assert np.array_equal(lg.argmax(1), z["argmax"])
+    loss = F.cross_entropy(out, t)
+    np.testing.assert_allclose(float(loss.detach()), float(z["loss"][0]), rtol=2e-5)
+    loss.backward()
+    for k, p in m.named_parameters():
+        close(p.grad.cpu().numpy(), z["g/" + k], k, 2e-3)
+    sd = m.state_dict()
+    for k in z.files:
+        if k.startswith("b1/") and "running" in k:
+            close(sd[k[3:]].cpu().numpy(), z[k], k, 1e-4)
+    m.eval()
+    with torch.no_grad():
+        close(m(x).cpu().numpy(), z["logits_eval"], "logits_eval", 2e-5, 1.0)
+
+
+@pytest.mark.parametrize("name", NETS)
+def test_bf16_network_is_close_and_trains(golden_dir, name):
+    z, m = load_net(golden_dir, name, "bf16")
+    x, t = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["target"]).cuda()
+    out = m(x)
+    ref = z["logits"]
+    err = np.abs(out.detach().cpu().numpy() - ref)
+    assert err.max() < 0.08 * max(1.0, np.abs(ref).max()) and err.mean() < 0.012 * max(1.0, np.abs(ref).mean())
+    loss = F.cross_entropy(out, t)
+    np.testing.assert_allclose(float(loss.detach()), float(z["loss"][0]), rtol=2e-2)
+    loss.backward()
+    cos = []
+    for k, p in m.named_parameters():
+        a, b = p.grad.flatten().double().cpu(), torch.from_numpy(z["g/" + k]).flatten().double()
+        if float(b.norm()) > 1e-6 and b.numel() >= 8:
+            cos.append(float(a @ b / (a.norm() * b.norm() + 1e-30)))
+    assert np.mean(cos) > 0.9, (name, cos)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        l = F.cross_entropy(m(x), t)
+        l.backward()
+        opt.step()
+        losses.append(float(l))
+    assert losses[-1] < losses[0], losses
+
+
+def test_api_edges_like_reference(golden_dir):
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Lesions_Segment.ReLayNet_2017 import ReLayNet
+    api = np.load(os.path.join(golden_dir, "relaynet_api.npz"))
+    assert "Sizes of tensors must match" in str(api["negative_msg"])
+    m = ReLayNet(1, 4, num_filters=4, compute_dtype="f32").cuda()
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        m(torch.zeros(1, 1, 20, 24, device="cuda"))         # 20 / 8 is not whole: the reference fails at torch.cat too
+    out = m(torch.randn(1, 1, 24, 16, device="cuda"))
+    assert out.shape == (1, 4, 24, 16)                       # logits (the reference never applies its Softmax2d)
+    assert float((out.softmax(1).sum(1) - 1).abs().max()) < 1e-5
+
+
+def test_headline_width_7x3_convolution_matches_torch():
+    """num_filters = 64 (the reference default) at 2 x 64 x 96: the 7x3 kernels on K = 21*64 and 21*128 (concat),
+    fp32 mode against stock torch's convolution of the same weights on the device."""
+    from oracle.torch_relaynet import TorchReLayNet
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Lesions_Segment.ReLayNet_2017 import ReLayNet
+    torch.manual_seed(3)
+    m = ReLayNet(1, 10, compute_dtype="f32").cuda().train()
+    ref = TorchReLayNet(1, 10, 64)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    ref = ref.double().train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 64, 96, generator=g)
+    t = torch.randint(0, 10, (2, 64, 96), generator=g)
+    out = m(x.cuda())
+    ro = ref(x.double())
+    close(out.detach().cpu().numpy(), ro.detach().numpy(), "logits", 5e-5, 1.0)
+    F.cross_entropy(out, t.cuda()).backward()
+    F.cross_entropy(ro, t).backward()
+    rg = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        close(p.grad.cpu().numpy(), rg[k].grad.numpy(), k, 5e-3)
