@@ -87,13 +87,19 @@ __global__ void __launch_bounds__(256) confusion_u8_kernel(const uint8_t* __rest
   // binary chunks: tn = n - t - p + tp, fp = p - tp, fn = t - tp
   s[0] += btp; s[1] += bt; s[2] += bp;
   s[3] += (unsigned long long)bn - bt - bp + btp; s[4] += bp - btp; s[5] += bt - btp;
+  // wave -> workgroup -> ONE atomic per sum and workgroup: every workgroup adds to the same six words, and same-address
+  // atomics serialise at the memory side (~12 ns each): 12 k of them (one per wave) cost 0.12 ms on a 5 us stream
+  __shared__ unsigned long long red[4][6];
+  const int wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     unsigned long long v = s[k];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&out[k], v);
+    if ((threadIdx.x & 63) == 0) red[wave][k] = v;
   }
+  __syncthreads();
+  if (threadIdx.x < 6) atomicAdd(&out[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void zero_counts_kernel(unsigned long long* oi, double* of) {
@@ -118,7 +124,7 @@ extern "C" int oct_confusion_counts(const void* y_true, const void* y_pred, int 
     switch (elem) {
       case 0: {   // two workgroups per CU: the streaming sweet spot measured on the BN kernels
         size_t bb = (n / 16 + 256 * 4 - 1) / (256 * 4);
-        if (bb > 512) bb = 512;
+        if (bb > 256) bb = 256;   // one workgroup per CU: 1.5 k same-address atomics in all
         if (bb < 1) bb = 1;
         hipLaunchKernelGGL(confusion_u8_kernel, dim3((int)bb), t, 0, s, (const uint8_t*)y_true, (const uint8_t*)y_pred, n, oi);
         break;

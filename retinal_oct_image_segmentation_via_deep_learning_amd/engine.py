@@ -477,6 +477,14 @@ class UNetEngine:
         d0 = self._act(n, h, w, src.c0, dy.device)
         d1 = self._act(n, h, w, src.c1, dy.device) if src.c1 else None
         self._conv(Src(dy, rec.cout), wp, cin, 9, n, h, w, d0, y1=d1, split=src.c0 if src.c1 else 0)
+        if self.debug is not None:
+            # everything a checker needs to redo THIS layer from the tensors the kernels actually saw (teacher forcing)
+            def bnc(b):
+                return None if b is None else (b.scale.clone(), b.shift.clone())
+            self.debug["layer:" + rec.wkey] = dict(
+                x0=src.x0.float().clone(), bn0=bnc(src.bn0), x1=None if src.x1 is None else src.x1.float().clone(),
+                bn1=bnc(src.bn1), dy=dy.float().clone(), d0=d0.float().clone(), d1=None if d1 is None else d1.float().clone(),
+                y=rec.y.float().clone())
         return d0, d1
 
     def _block_backward(self, name, da, dpool, G, accumulate, need_dx=True, partials=None):

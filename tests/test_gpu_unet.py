@@ -118,22 +118,24 @@ def rel_l2(got, ref):
     return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
 
 
-def bf16_against_rounding_aware_oracle(model, state, x, t, w_ce, w_dice, eps, tag):
-    """bf16 HIP step vs oracle/ref_cpu.OracleUNet(storage="bf16"): the same network with a bf16 rounding at every
-    point where the HIP path stores bf16.  What is left between the two is fp32-vs-fp64 accumulation order, i.e.
-    a 1-ulp difference on ~1e-4 of the stored elements -- so the bounds are per-tensor and tight, instead of the
-    cosine floor a comparison with the unrounded reference needs (bf16 flips ~1 % of the ReLU masks)."""
+def bf16_against_rounding_aware_oracle(model, state, x, t, w_ce, w_dice, eps, tag, grad_tol=(0.35, 0.12)):
+    """bf16 HIP step vs oracle/ref_cpu.OracleUNet(storage="bf16", dtype=float32): the same network with a bf16
+    rounding at every point where the HIP path stores bf16, accumulating in fp32 like the MFMA does.  Forward
+    quantities (probabilities, arg-max, loss) agree tightly.  Gradients of a FREE-RUNNING comparison cannot: a
+    1-ulp difference (summation order) in an early layer shifts the small-batch BatchNorm statistics of the deep
+    levels and re-rounds most of the network, so the per-tensor bound here is loose and the tight per-layer bound
+    lives in test_headline_width_bf16_layers_teacher_forced_against_oracle."""
     from oracle import ref_cpu
-    net = ref_cpu.OracleUNet(state, storage="bf16")
+    net = ref_cpu.OracleUNet(state, dtype=np.float32, storage="bf16")
     rp, (rl, rce, rdice), rg = net.loss_and_grads(x.numpy(), t.numpy(), w_ce, w_dice, eps)
     loss, probs = model.forward_backward(x.cuda(), t.cuda(), w_ce, w_dice, eps, want_probs=True)
     torch.cuda.synchronize()
     p = probs.cpu().numpy()
-    assert np.abs(p - rp).max() < 1e-2, (tag, np.abs(p - rp).max())
+    assert np.abs(p - rp).max() < 2e-2, (tag, np.abs(p - rp).max())
     top2 = np.sort(rp, axis=1)[:, -2:]
-    safe = (top2[:, 1] - top2[:, 0]) > 2e-2
-    assert safe.mean() > 0.5 and np.array_equal(p.argmax(1)[safe], rp.argmax(1)[safe]), tag
-    np.testing.assert_allclose(loss.cpu().numpy()[0], rl, rtol=2e-3, err_msg=tag)
+    safe = (top2[:, 1] - top2[:, 0]) > 4e-2
+    assert safe.mean() > 0.3 and np.array_equal(p.argmax(1)[safe], rp.argmax(1)[safe]), tag
+    np.testing.assert_allclose(loss.cpu().numpy()[0], rl, rtol=3e-3, err_msg=tag)
     worst = []
     for k, prm in model.named_parameters():
         g = prm.grad.detach().cpu().numpy()
@@ -141,7 +143,7 @@ def bf16_against_rounding_aware_oracle(model, state, x, t, w_ce, w_dice, eps, ta
             continue
         worst.append((rel_l2(g, rg[k]), k))
     worst.sort(reverse=True)
-    assert worst[0][0] < 3e-2 and np.mean([w for w, _ in worst]) < 1e-2, (tag, worst[:5])
+    assert worst[0][0] < grad_tol[0] and np.mean([w for w, _ in worst]) < grad_tol[1], (tag, worst[:5])
     return worst
 
 
@@ -406,3 +408,55 @@ def test_disable_v2_switch_runs_the_headline_width_in_bf16():
         assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
         outs[flag] = float(r.stdout.split()[-1])
     assert abs(outs["1"] - outs["0"]) < 0.05 * abs(outs["0"])
+
+
+def test_headline_width_bf16_layers_teacher_forced_against_oracle(golden_dir):
+    """Every 3x3 layer of the benchmarked network, IN SITU: the bf16 step runs once on the reference-pinned wide
+    fixture, and each layer is then redone by the oracle from the tensors the kernels actually read (its own bf16
+    inputs, BatchNorm coefficients and incoming dY).  Errors cannot compound this way, so the bound is the one a single
+    bf16 store allows -- a free-running comparison cannot have it: with bf16 storage a 1-ulp difference in an early
+    layer moves the small-batch BatchNorm statistics of the deep levels and re-rounds most of the network (measured:
+    78 % of the bottleneck's elements differ by a few ulps between fp32- and fp64-accumulating evaluations)."""
+    from oracle import ref_cpu as R
+    (z, state, x, t, model), _ = _wide_fixture(golden_dir)
+    model = model.cuda().train().set_compute_dtype("bf16")
+    model._engine.debug = {}
+    model.forward_backward(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    dbg, model._engine.debug = model._engine.debug, None
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+    layers = [k for k in dbg if k.startswith("layer:")]
+    assert len(layers) == 17                       # 18 convs minus the first layer (its backward is one fused kernel)
+
+    def nchw(tn):
+        return tn.cpu().numpy().transpose(0, 3, 1, 2).astype(np.float64)
+
+    def act(xk, bn):
+        a = nchw(xk)
+        if bn is not None:
+            sc, sh = (v.cpu().numpy().astype(np.float64) for v in bn)
+            a = R.round_bf16(np.maximum(a * sc[None, :, None, None] + sh[None, :, None, None], 0))
+        return a
+
+    def ulps(got, ref):
+        d = np.abs(got - ref)
+        return d / np.maximum(2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-30))) - 7), 1e-30)   # bf16 spacing at |ref|
+
+    for key in layers:
+        rec, wk = dbg[key], key[6:]
+        a = act(rec["x0"], rec["bn0"])
+        if rec["x1"] is not None:
+            a = np.concatenate([a, act(rec["x1"], rec["bn1"])], axis=1)
+        wq = R.round_bf16(state[wk])
+        # forward: y = bf16(conv(a, w)): all but a handful of elements identical, none further than one rounding away
+        y_ref = R.conv3x3_fwd(a, wq)
+        u = ulps(nchw(rec["y"]), R.round_bf16(y_ref))
+        assert (u > 0).mean() < 1e-2 and (u > 1.01).mean() < 1e-4 and u.max() < 64, (wk, "fprop", (u > 0).mean(), u.max())
+        # backward from the dY this layer received
+        dy = nchw(rec["dy"])
+        dx_ref, dw_ref = R.conv3x3_bwd(a, wq, dy)
+        assert rel_l2(grads[wk], dw_ref) < 2e-3, (wk, "wgrad", rel_l2(grads[wk], dw_ref))
+        dx = nchw(rec["d0"]) if rec["d1"] is None else np.concatenate([nchw(rec["d0"]), nchw(rec["d1"])], axis=1)
+        u = ulps(dx, R.round_bf16(dx_ref))
+        # (a heavily cancelling sum can sit several bf16 ulps of its own small value away from the fp32 accumulation)
+        assert (u > 0).mean() < 1e-2 and (u > 1.01).mean() < 1e-4 and u.max() < 64, (wk, "dgrad", (u > 0).mean(), u.max())
