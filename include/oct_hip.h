@@ -58,6 +58,11 @@ extern "C" {
 #define OCT_PACK_DECONV_DGRAD 3 /* (Cin,Cout,2,2): row=ci,  k=(dydx,co)              */
 #define OCT_PACK_1X1_DGRAD 4    /* (Cout,Cin,1,1): row=ci,  k=co                     */
 #define OCT_PACK_1X1_FPROP 5    /* (Cout,Cin,1,1): row=co,  k=ci                     */
+/* 3-D (oct_pack_weights3d): Conv3d(3x3x3) and ConvTranspose3d(k=2,s=2) of the cfg5 volumetric U-Net */
+#define OCT_PACK_CONV3D_FPROP 6   /* (Cout,Cin,3,3,3): row=co, taps=(kh,kw), k=(kd,ci)                        */
+#define OCT_PACK_CONV3D_DGRAD 7   /* (Cout,Cin,3,3,3): row=ci, k=(kd,co), kernel point-reflected in d, h, w   */
+#define OCT_PACK_DECONV3D_FPROP 8 /* (Cin,Cout,2,2,2), one depth slice kdi: row=(dydx,co), k=ci              */
+#define OCT_PACK_DECONV3D_DGRAD 9 /* (Cin,Cout,2,2,2): row=ci, k=(kd,dydx,co)                                */
 
 const char* oct_version_string(void);
 int oct_version(void);
@@ -87,6 +92,13 @@ typedef struct OctConvDesc {
   int want_stats;    /* write per-workgroup partial sum / sum of squares of the fp32 outputs */
   int kh, kw;        /* kernel size; 0, 0 = derive from taps (9 -> 3x3, 1 -> 1x1).  7, 3 with taps = 21 is ReLayNet's
                       * BasicBlock conv (ReLayNet_2017.py:155-160): stride 1, padding ((kh-1)/2, (kw-1)/2), plain in/out */
+  int depth;         /* 0: 2-D.  D > 0: the n images are n/D volumes of D slices each (NDHWC) and the GEMM gains depth taps:
+                      *   taps 9, plain in : Conv3d 3x3x3, padding 1 -- K = 3*(c0+c1), tap kd reads slice d+kd-1 (zero outside
+                      *                      the volume); weights packed OCT_PACK_CONV3D_FPROP / _DGRAD
+                      *   taps 1, IN_S2D   : ConvTranspose3d(k2,s2) data gradient -- K = 8*c0, k = (kd,dy,dx,c) gathers from
+                      *                      slice 2d+kd of the 2D x 2H x 2W tensor; weights OCT_PACK_DECONV3D_DGRAD        */
+  int out_img_mul, out_img_add; /* OUT_D2S only, 0,0 = identity: the output image index is img*mul + add.  ConvTranspose3d
+                      * forward = two D2S launches (kd = 0, 1) with mul = 2, add = kd and the OCT_PACK_DECONV3D_FPROP slice */
 } OctConvDesc;
 
 typedef struct OctConvArgs {
@@ -109,6 +121,9 @@ int oct_pack_weights(int mode, int dtype, const float* w, void* wpacked, int cou
  * (buffer: oct_packed_weight_elems(rows, kh*kw, kch)); ReLayNet_2017.py:155-160 uses 7x3.                  */
 int oct_pack_weights_kk(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int kh, int kw,
                         void* stream);
+/* The OCT_PACK_*3D modes (buffer: oct_packed_weight_elems(rows, taps, kch) with rows/taps/kch = cout/9/3cin, cin/9/3cout,
+ * 4cout/1/cin, cin/1/8cout).  kdi: depth slice for OCT_PACK_DECONV3D_FPROP, 0 otherwise.                         */
+int oct_pack_weights3d(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int kdi, void* stream);
 /* The same for up to OCT_PACK_BATCH_MAX weights per launch (all re-packings that follow an optimizer
  * step in one go); longer lists are split.  Jobs are plain structs read on the host.              */
 #define OCT_PACK_BATCH_MAX 96
@@ -133,6 +148,11 @@ typedef struct OctWgradDesc {
   int xform0, xform1;
   int dy_mode;
   int kh, kw;        /* as in OctConvDesc; dwp is [kh*kw][cout][ktot] */
+  int depth;         /* D > 0: volumes of D slices (see OctConvDesc).  One launch computes the weight gradient of ONE depth
+                      * tap: the input tile is read from slice d + in_img_shift (zero outside the volume)              */
+  int in_img_shift;  /* -1, 0, +1 = kd - 1 (Conv3d); 0 otherwise                                                       */
+  int dy_img_mul, dy_img_add; /* dy_mode S2D only, 0,0 = identity: dY is gathered from image img*mul + add
+                      * (ConvTranspose3d weight gradient: two launches, mul = 2, add = kd)                               */
 } OctWgradDesc;
 typedef struct OctWgradArgs {
   const void* x0; const void* x1;
@@ -155,6 +175,9 @@ int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d);
 int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cout, int cin, int accumulate, void* stream);
 /* dwp[kh*kw][cout][cin] -> grad (Cout,Cin,kh,kw) for any kernel size */
 int oct_unpack_wgrad_kk(const float* dwp, float* grad, int cout, int cin, int kh, int kw, int accumulate, void* stream);
+/* 3-D: OCT_PACK_CONV3D_FPROP   dwp[3][9][cout][cin] (three launches, one slab per depth tap) -> grad (Cout,Cin,3,3,3)
+ *      OCT_PACK_DECONV3D_FPROP dwp[0][(dydx,co)][ci] of depth slice kdi -> grad (Cin,Cout,2,2,2)[:, :, kdi]          */
+int oct_unpack_wgrad3d(int mode, const float* dwp, float* grad, int cout, int cin, int kdi, int accumulate, void* stream);
 /* The same for up to OCT_PACK_BATCH_MAX gradients per launch (a whole backward pass).               */
 typedef struct OctUnpackJob {
   int mode, cout, cin, accumulate;
@@ -333,6 +356,13 @@ int oct_index_scatter(int dtype, const void* v, const int64_t* idx, void* out, i
                       void* stream);
 int oct_index_gather(int dtype, const void* x, const int64_t* idx, void* v, int n, size_t npool, size_t plane, int c,
                      void* stream);
+
+/* MaxPool3d(2) of the cfg5 volumetric U-Net = oct_bn_relu_pool_fwd inside every slice, then the pairwise maximum of
+ * consecutive slices: p2 (nslab, 2, m) -> out (nslab, m), m contiguous elements per slice ((h/2)*(w/2)*c).  Backward:
+ * dout goes to the first slice unless the second is strictly larger (torch's first-maximum rule in (d,h,w) order);
+ * the 2-D routing inside the slice is oct_dact_bn_reduce's.                                                   */
+int oct_depth_pool_fwd(int dtype, const void* p2, void* out, size_t nslab, size_t m, void* stream);
+int oct_depth_pool_bwd(int dtype, const void* p2, const void* dout, void* dp2, size_t nslab, size_t m, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Metrics (Metrics/Region_based_metrics.py:3-61, Metrics/ConfusionMatrix_based_metrics.py:4-63)

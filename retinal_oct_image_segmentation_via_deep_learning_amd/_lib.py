@@ -21,6 +21,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ACT_PRELU = 3   # host-side tag only: PReLU has its own entry points (oct_affine_prelu_fwd / _bwd)
 OUT_PLAIN, OUT_D2S = 0, 1
 PACK_CONV_FPROP, PACK_CONV_DGRAD, PACK_DECONV_FPROP, PACK_DECONV_DGRAD, PACK_1X1_DGRAD, PACK_1X1_FPROP = range(6)
+PACK_CONV3D_FPROP, PACK_CONV3D_DGRAD, PACK_DECONV3D_FPROP, PACK_DECONV3D_DGRAD = 6, 7, 8, 9
 MAX_CLASSES = 16
 HEAD_LOSS_SLOTS = 2 + 3 * MAX_CLASSES
 
@@ -43,7 +44,7 @@ PACK_BATCH_MAX = 96
 class ConvDesc(C.Structure):
     _fields_ = [(k, c_int) for k in (
         "dtype", "n", "h", "w", "c0", "c1", "cout", "taps", "xform0", "xform1", "in_mode", "out_mode",
-        "split", "want_stats", "kh", "kw")]
+        "split", "want_stats", "kh", "kw", "depth", "out_img_mul", "out_img_add")]
 
 
 class ConvArgs(C.Structure):
@@ -53,7 +54,8 @@ class ConvArgs(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [(k, c_int) for k in (
-        "dtype", "n", "h", "w", "c0", "c1", "cout", "taps", "xform0", "xform1", "dy_mode", "kh", "kw")]
+        "dtype", "n", "h", "w", "c0", "c1", "cout", "taps", "xform0", "xform1", "dy_mode", "kh", "kw", "depth",
+        "in_img_shift", "dy_img_mul", "dy_img_add")]
 
 
 class WgradArgs(C.Structure):
@@ -75,6 +77,10 @@ SIGNATURES = {
     "oct_conv_stat_blocks": (c_int, [C.POINTER(ConvDesc)]),
     "oct_packed_weight_elems": (c_size_t, [c_int, c_int, c_int]),
     "oct_pack_weights": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "oct_pack_weights3d": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "oct_unpack_wgrad3d": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_depth_pool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "oct_depth_pool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "oct_pack_weights_kk": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_unpack_wgrad_kk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_affine_prelu_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),

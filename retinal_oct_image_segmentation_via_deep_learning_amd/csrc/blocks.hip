@@ -562,3 +562,61 @@ extern "C" int oct_index_gather(int dtype, const void* x, const int64_t* idx, vo
   else OCT_CHECK(false, "oct_index_gather: bad dtype");
   return oct_check_launch("index_gather");
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool3d(2) = 2x2 pooling inside every slice (oct_bn_relu_pool_fwd) followed by THIS pairwise maximum over
+// consecutive slices; the first maximum in torch's (d, h, w) scanning order is "slice 0 unless slice 1 is strictly
+// larger", so the backward routing decomposes the same way: oct_depth_pool_bwd, then the 2-D routing of
+// oct_dact_bn_reduce.  p2: (nvol, 2*dout, m) with m = (h/2)*(w/2)*c contiguous elements per slice.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void depth_pool_fwd_kernel(const T* __restrict__ p2, T* __restrict__ out, size_t nslab, size_t mvec) {
+  const size_t total = nslab * mvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t slab = i / mvec, e = i - slab * mvec;
+    float a[V], b[V];
+    load_vec<T, V>(p2 + ((2 * slab) * mvec + e) * V, a);
+    load_vec<T, V>(p2 + ((2 * slab + 1) * mvec + e) * V, b);
+#pragma unroll
+    for (int j = 0; j < V; ++j) a[j] = fmaxf(a[j], b[j]);
+    store_vec<T, V>(out + i * V, a);
+  }
+}
+template <typename T, int V>
+__global__ void depth_pool_bwd_kernel(const T* __restrict__ p2, const T* __restrict__ dout, T* __restrict__ dp2, size_t nslab,
+                                      size_t mvec) {
+  const size_t total = nslab * mvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t slab = i / mvec, e = i - slab * mvec;
+    float a[V], b[V], d[V], d0[V], d1[V];
+    load_vec<T, V>(p2 + ((2 * slab) * mvec + e) * V, a);
+    load_vec<T, V>(p2 + ((2 * slab + 1) * mvec + e) * V, b);
+    load_vec<T, V>(dout + i * V, d);
+#pragma unroll
+    for (int j = 0; j < V; ++j) { const bool second = b[j] > a[j]; d0[j] = second ? 0.f : d[j]; d1[j] = second ? d[j] : 0.f; }
+    store_vec<T, V>(dp2 + ((2 * slab) * mvec + e) * V, d0);
+    store_vec<T, V>(dp2 + ((2 * slab + 1) * mvec + e) * V, d1);
+  }
+}
+extern "C" int oct_depth_pool_fwd(int dtype, const void* p2, void* out, size_t nslab, size_t m, void* stream) {
+  OCT_CHECK(p2 && out && nslab > 0 && m > 0, "oct_depth_pool_fwd: bad args");
+  const int v = (m % 8 == 0) ? 8 : 1;
+  const int blocks = bk_blocks(nslab * (m / v));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, V) hipLaunchKernelGGL((depth_pool_fwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)p2, (T*)out, nslab, m / V)
+  BK_DISPATCH("oct_depth_pool_fwd");
+#undef LAUNCH
+  return oct_check_launch("depth_pool_fwd");
+}
+extern "C" int oct_depth_pool_bwd(int dtype, const void* p2, const void* dout, void* dp2, size_t nslab, size_t m, void* stream) {
+  OCT_CHECK(p2 && dout && dp2 && nslab > 0 && m > 0, "oct_depth_pool_bwd: bad args");
+  const int v = (m % 8 == 0) ? 8 : 1;
+  const int blocks = bk_blocks(nslab * (m / v));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, V) hipLaunchKernelGGL((depth_pool_bwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)p2, \
+                                        (const T*)dout, (T*)dp2, nslab, m / V)
+  BK_DISPATCH("oct_depth_pool_bwd");
+#undef LAUNCH
+  return oct_check_launch("depth_pool_bwd");
+}

@@ -23,6 +23,10 @@ struct IgemmParams {
   int cout, nb32;
   int xf0, xf1, in_mode, out_mode, split;
   int tiles_x, tiles_y;
+  // 3-D (volumes stored as n = N*D images): depth = D enables the depth taps.  Plain input: K = 3 * csrc, tap kdi reads
+  // image img + kdi - 1 of the same volume (zero outside); S2D input (ConvTranspose3d dgrad): K = 8 * c0, k = (kdi, dy, dx, c)
+  // gathers from image 2*img + kdi.  D2S output: image index = img * oimg_mul + oimg_add (ConvTranspose3d: 2*img + kdi).
+  int depth, csrc, oimg_mul, oimg_add;
 };
 
 // ---- staging: 8 consecutive K-channels of one input pixel, transformed, as floats ------------
@@ -30,11 +34,20 @@ template <typename T>
 __device__ __forceinline__ float fetch1(const IgemmParams& p, int img, int iy, int ix, int k) {
   if (k >= p.ktot) return 0.f;
   if (p.in_mode == OCT_IN_S2D) {
-    const int dydx = k / p.c0, c = k - dydx * p.c0;
+    int dydx = k / p.c0;
+    const int c = k - dydx * p.c0;
+    if (p.depth > 0) { img = 2 * img + (dydx >> 2); dydx &= 3; }
     const size_t pix = ((size_t)img * (2 * p.h) + (2 * iy + (dydx >> 1))) * (size_t)(2 * p.w) + (2 * ix + (dydx & 1));
     float v = to_f32(reinterpret_cast<const T*>(p.x0)[pix * p.c0 + c]);
     if (p.xf0) v = fmaxf(fmaf(v, p.sc0[c], p.sh0[c]), 0.f);
     return v;
+  }
+  if (p.depth > 0) {
+    const int kdi = k / p.csrc;
+    k -= kdi * p.csrc;
+    const int dz = img % p.depth + kdi - 1;
+    if (dz < 0 || dz >= p.depth) return 0.f;
+    img += kdi - 1;
   }
   const size_t pix = ((size_t)img * p.h + iy) * (size_t)p.w + ix;
   if (k < p.c0) {
@@ -55,15 +68,32 @@ __device__ __forceinline__ void fetch8(const IgemmParams& p, int img, int iy, in
   size_t pix = 0;
   if (p.in_mode == OCT_IN_S2D) {
     if ((p.c0 & 7) == 0 && k + 8 <= p.ktot) {
-      const int dydx = k / p.c0; c = k - dydx * p.c0; cs = p.c0;
-      pix = ((size_t)img * (2 * p.h) + (2 * iy + (dydx >> 1))) * (size_t)(2 * p.w) + (2 * ix + (dydx & 1));
+      int dydx = k / p.c0; c = k - dydx * p.c0; cs = p.c0;
+      int im = img;
+      if (p.depth > 0) { im = 2 * img + (dydx >> 2); dydx &= 3; }
+      pix = ((size_t)im * (2 * p.h) + (2 * iy + (dydx >> 1))) * (size_t)(2 * p.w) + (2 * ix + (dydx & 1));
       src = reinterpret_cast<const T*>(p.x0); sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0;
     }
+  } else if (p.depth > 0 && ((p.csrc & 7) != 0 || k + 8 > p.ktot)) {
+    // depth taps on a channel count that is not a multiple of 8 (the 1-channel input volume): element by element
   } else {
-    pix = ((size_t)img * p.h + iy) * (size_t)p.w + ix;
+    int kk = k, im = img;
+    if (p.depth > 0) {
+      const int kdi = k / p.csrc;
+      kk = k - kdi * p.csrc;
+      const int dz = img % p.depth + kdi - 1;
+      if (dz < 0 || dz >= p.depth) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        return;
+      }
+      im = img + kdi - 1;
+    }
+    const int k = kk;   // channel inside the (virtually concatenated) source of this depth tap
+    pix = ((size_t)im * p.h + iy) * (size_t)p.w + ix;
     if ((p.c0 & 7) == 0 && k + 8 <= p.c0) {
       src = reinterpret_cast<const T*>(p.x0); c = k; cs = p.c0; sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0;
-    } else if ((p.c0 & 7) == 0 && (p.c1 & 7) == 0 && k >= p.c0 && k + 8 <= p.ktot) {
+    } else if ((p.c0 & 7) == 0 && (p.c1 & 7) == 0 && k >= p.c0 && k + 8 <= p.c0 + p.c1) {
       src = reinterpret_cast<const T*>(p.x1); c = k - p.c0; cs = p.c1; sc = p.sc1; sh = p.sh1; xf = p.xf1 != 0;
     }
   }
@@ -88,6 +118,7 @@ __device__ __forceinline__ void fetch8(const IgemmParams& p, int img, int iy, in
 template <typename T>
 __device__ __forceinline__ void store4(const IgemmParams& p, int img, int oy, int ox, int cb, const float (&v)[4]) {
   if (p.out_mode == OCT_OUT_D2S) {
+    if (p.oimg_mul) img = img * p.oimg_mul + p.oimg_add;
     const int cr = p.cout >> 2;  // real output channels
     if ((cr & 3) == 0 && cb + 3 < p.cout) {
       const int dydx = cb / cr, co = cb - dydx * cr;
@@ -283,7 +314,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 // filter is the point reflection of the kernel, i.e. the reversed flat tap index
 template <typename T>
 __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, T* __restrict__ wp, int cout, int cin,
-                                    int rows, int taps, int kch, int nk16, size_t total) {
+                                    int rows, int taps, int kch, int nk16, size_t total, int kdi = 0) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int j = i & 7;
     const int lane = (i >> 3) & 63;
@@ -307,6 +338,18 @@ __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, T* __
         v = w[((size_t)row * cout + co) * 4 + dydx];
       } else if (mode == OCT_PACK_1X1_DGRAD) {      // row = ci, k = co
         v = w[(size_t)k * cin + row];
+      } else if (mode == OCT_PACK_CONV3D_FPROP) {   // (Cout,Cin,3,3,3): row = co, k = (kd, ci), tap = (kh, kw)
+        const int kd = k / cin, ci = k - kd * cin;
+        v = w[(((size_t)row * cin + ci) * 3 + kd) * 9 + tap];
+      } else if (mode == OCT_PACK_CONV3D_DGRAD) {   // row = ci, k = (kd, co), kernel point-reflected in all three axes
+        const int kd = k / cout, co = k - kd * cout;
+        v = w[(((size_t)co * cin + row) * 3 + (2 - kd)) * 9 + (8 - tap)];
+      } else if (mode == OCT_PACK_DECONV3D_FPROP) { // (Cin,Cout,2,2,2), depth slice kdi: row = dydx*cout + co, k = ci
+        const int dydx = row / cout, co = row - dydx * cout;
+        v = w[(((size_t)k * cout + co) * 2 + kdi) * 4 + dydx];
+      } else if (mode == OCT_PACK_DECONV3D_DGRAD) { // row = ci, k = (kd, dydx, co)
+        const int q = k / cout, co = k - q * cout;
+        v = w[(((size_t)row * cout + co) * 2 + (q >> 2)) * 4 + (q & 3)];
       } else {                                      // 1X1_FPROP: row = co, k = ci
         v = w[(size_t)row * cin + k];
       }
@@ -322,6 +365,10 @@ static void pack_dims(int mode, int cout, int cin, int* rows, int* taps, int* kc
     case OCT_PACK_DECONV_FPROP: *rows = 4 * cout; *taps = 1; *kch = cin; break;
     case OCT_PACK_DECONV_DGRAD: *rows = cin; *taps = 1; *kch = 4 * cout; break;
     case OCT_PACK_1X1_DGRAD: *rows = cin; *taps = 1; *kch = cout; break;
+    case OCT_PACK_CONV3D_FPROP: *rows = cout; *taps = 9; *kch = 3 * cin; break;
+    case OCT_PACK_CONV3D_DGRAD: *rows = cin; *taps = 9; *kch = 3 * cout; break;
+    case OCT_PACK_DECONV3D_FPROP: *rows = 4 * cout; *taps = 1; *kch = cin; break;
+    case OCT_PACK_DECONV3D_DGRAD: *rows = cin; *taps = 1; *kch = 8 * cout; break;
     default: *rows = cout; *taps = 1; *kch = cin; break;
   }
 }
@@ -330,9 +377,15 @@ extern "C" size_t oct_packed_weight_elems(int rows, int taps, int kch) {
   return (size_t)ceil_div(rows, 32) * taps * ceil_div(kch, 16) * 512;
 }
 
-static int pack_weights_impl(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int taps_kk, void* stream);
+static int pack_weights_impl(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int taps_kk, void* stream, int kdi = 0);
 extern "C" int oct_pack_weights(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, void* stream) {
+  OCT_CHECK(mode >= 0 && mode <= 5, "oct_pack_weights: bad mode %d", mode);
   return pack_weights_impl(mode, dtype, w, wpacked, cout, cin, 0, stream);
+}
+extern "C" int oct_pack_weights3d(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int kdi, void* stream) {
+  OCT_CHECK(mode >= OCT_PACK_CONV3D_FPROP && mode <= OCT_PACK_DECONV3D_DGRAD, "oct_pack_weights3d: bad mode %d", mode);
+  OCT_CHECK(kdi == 0 || (mode == OCT_PACK_DECONV3D_FPROP && kdi == 1), "oct_pack_weights3d: kdi selects the depth slice of DECONV3D_FPROP (0 or 1)");
+  return pack_weights_impl(mode, dtype, w, wpacked, cout, cin, 0, stream, kdi);
 }
 extern "C" int oct_pack_weights_kk(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int kh, int kw,
                                    void* stream) {
@@ -340,8 +393,8 @@ extern "C" int oct_pack_weights_kk(int mode, int dtype, const float* w, void* wp
   OCT_CHECK(kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && kh * kw <= 49, "oct_pack_weights_kk: odd kernel sizes up to 7x7 (got %dx%d)", kh, kw);
   return pack_weights_impl(mode, dtype, w, wpacked, cout, cin, kh * kw, stream);
 }
-static int pack_weights_impl(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int taps_kk, void* stream) {
-  OCT_CHECK(mode >= 0 && mode <= 5, "oct_pack_weights: bad mode %d", mode);
+static int pack_weights_impl(int mode, int dtype, const float* w, void* wpacked, int cout, int cin, int taps_kk, void* stream, int kdi) {
+  OCT_CHECK(mode >= 0 && mode <= OCT_PACK_DECONV3D_DGRAD, "oct_pack_weights: bad mode %d", mode);
   OCT_CHECK(cout > 0 && cin > 0 && w && wpacked, "oct_pack_weights: bad arguments");
   int rows, taps, kch;
   pack_dims(mode, cout, cin, &rows, &taps, &kch);
@@ -351,10 +404,10 @@ static int pack_weights_impl(int mode, int dtype, const float* w, void* wpacked,
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (dtype == OCT_DT_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), mode, w,
-                       (bf16_t*)wpacked, cout, cin, rows, taps, kch, nk16, total);
+                       (bf16_t*)wpacked, cout, cin, rows, taps, kch, nk16, total, kdi);
   else if (dtype == OCT_DT_F32)
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), mode, w,
-                       (float*)wpacked, cout, cin, rows, taps, kch, nk16, total);
+                       (float*)wpacked, cout, cin, rows, taps, kch, nk16, total, kdi);
   else
     OCT_CHECK(false, "oct_pack_weights: bad dtype %d", dtype);
   return oct_check_launch("pack_weights");
@@ -432,7 +485,7 @@ static TileCfg pick_cfg(int cout) {
 extern "C" int oct_conv_stat_blocks(const OctConvDesc* d) {
   if (!d) return 0;
   if (d->kh != 7) {
-    const int f1 = oct_first_stat_rows(d);
+    const int f1 = d->depth > 0 ? -1 : oct_first_stat_rows(d);
     if (f1 >= 0) return f1;
     const int v2 = oct_conv_v2_stat_rows(d);
     if (v2 >= 0) return v2;
@@ -484,6 +537,9 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
             "oct_conv_forward: kernel must be 3x3 (taps 9), 1x1 (taps 1) or 7x3 (taps 21, kh=7, kw=3); got taps=%d kh=%d kw=%d",
             d->taps, d->kh, d->kw);
   OCT_CHECK(kh != 7 || (d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN), "oct_conv_forward: 7x3 runs plain -> plain");
+  OCT_CHECK(d->depth >= 0 && (d->depth == 0 || (d->n % d->depth) == 0), "oct_conv_forward: n=%d is not a whole number of depth-%d volumes", d->n, d->depth);
+  OCT_CHECK(d->depth == 0 || kh != 7, "oct_conv_forward: depth taps go with the 3x3 (3x3x3) and 1x1 (2x2x2 transposed) kernels");
+  OCT_CHECK(d->out_img_mul == 0 || d->out_mode == OCT_OUT_D2S, "oct_conv_forward: the output image map belongs to D2S");
   OCT_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->c0 > 0 && d->c1 >= 0 && d->cout > 0,
             "oct_conv_forward: bad shape n=%d h=%d w=%d c0=%d c1=%d cout=%d", d->n, d->h, d->w, d->c0, d->c1, d->cout);
   OCT_CHECK(a->x0 && a->wpacked && a->y0, "oct_conv_forward: null tensor");
@@ -497,7 +553,7 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
   OCT_CHECK(!(d->want_stats && !a->stat_partials), "oct_conv_forward: want_stats without buffer");
   OCT_CHECK((size_t)d->n * d->h * d->w < (1u << 31), "oct_conv_forward: too many pixels");
   if (kh != 7) {
-    int took = oct_first_fprop(d, a, stream);
+    int took = d->depth > 0 ? 0 : oct_first_fprop(d, a, stream);
     if (took == 0) took = oct_conv_forward_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
   }
@@ -506,7 +562,8 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
   p.wp = a->wpacked; p.bias = a->bias; p.y0 = a->y0; p.y1 = a->y1;
   p.stats = d->want_stats ? a->stat_partials : nullptr;
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1;
-  p.ktot = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
+  p.depth = d->depth; p.csrc = d->c0 + d->c1; p.oimg_mul = d->out_img_mul; p.oimg_add = d->out_img_add;
+  p.ktot = d->in_mode == OCT_IN_S2D ? (d->depth > 0 ? 8 : 4) * d->c0 : (d->depth > 0 ? 3 : 1) * (d->c0 + d->c1);
   p.nk16 = ceil_div(p.ktot, 16);
   p.cout = d->cout; p.nb32 = ceil_div(d->cout, 32);
   p.xf0 = d->xform0; p.xf1 = d->xform1; p.in_mode = d->in_mode; p.out_mode = d->out_mode; p.split = d->split;

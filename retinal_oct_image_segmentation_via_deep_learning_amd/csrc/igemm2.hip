@@ -732,6 +732,7 @@ static bool v2_enabled() {
 static V2Plan plan_v2(const OctConvDesc* d) {
   V2Plan pl = {};
   if (!v2_enabled()) return pl;
+  if (d->depth > 0 || d->out_img_mul != 0 || d->kh == 7) return pl;   // depth taps / 7x3: generic kernels
   const int cin = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
   // plain 3x3: any H, W (ragged last tiles are predicated); the deconv modes need whole tiles
   const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;

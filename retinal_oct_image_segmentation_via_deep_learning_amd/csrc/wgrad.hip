@@ -21,6 +21,8 @@ struct WgradParams {
   int xf0, xf1, dy_mode;
   int tiles_x, tiles_y, ntiles;
   int ty0, pad_h, pad_w;   // first kernel row this launch covers, "same" padding of the whole kernel
+  int depth, img_shift;    // 3-D: the input tile comes from slice d + img_shift of the same volume (zero outside)
+  int dy_mul, dy_add;      // S2D dY: gathered from image img*dy_mul + dy_add (0: identity)
 };
 
 template <typename T>
@@ -62,6 +64,7 @@ template <typename T>
 __device__ __forceinline__ void wg_fetch_dy8(const WgradParams& p, int img, int y, int x, int row, float (&v)[8]) {
   const T* dy = reinterpret_cast<const T*>(p.dy);
   if (p.dy_mode == OCT_IN_S2D) {
+    if (p.dy_mul) img = img * p.dy_mul + p.dy_add;
     const int cr = p.cout >> 2;
     if ((cr & 7) == 0 && row + 8 <= p.cout) {
       const int dydx = row / cr, co = row - dydx * cr;
@@ -128,8 +131,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       const int ly = pix / LW, lx = pix - ly * LW;
       const int iy = y0 + ly + p.ty0 - p.pad_h, ix = x0 + lx - p.pad_w;
       float v[8];
-      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
-        wg_fetch_in8<T>(p, ((size_t)img * p.h + iy) * (size_t)p.w + ix, ci0 + grp * 8, v);
+      const int dz = p.depth > 0 ? img % p.depth + p.img_shift : 0;
+      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w && dz >= 0 && (p.depth == 0 || dz < p.depth)) {
+        wg_fetch_in8<T>(p, ((size_t)(img + p.img_shift) * p.h + iy) * (size_t)p.w + ix, ci0 + grp * 8, v);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -198,6 +202,9 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
             "oct_conv_wgrad: kernel must be 3x3 (taps 9), 1x1 (taps 1) or 7x3 (taps 21, kh=7, kw=3); got taps=%d kh=%d kw=%d",
             d->taps, d->kh, d->kw);
   OCT_CHECK(kh != 7 || (d->dy_mode == OCT_IN_PLAIN && !a->dy_coef), "oct_conv_wgrad: 7x3 takes a plain dY");
+  OCT_CHECK(d->depth >= 0 && (d->depth == 0 || ((d->n % d->depth) == 0 && kh != 7)), "oct_conv_wgrad: bad depth %d for n=%d", d->depth, d->n);
+  OCT_CHECK(d->in_img_shift >= -1 && d->in_img_shift <= 1 && (d->in_img_shift == 0 || d->depth > 0), "oct_conv_wgrad: in_img_shift needs depth > 0");
+  OCT_CHECK(d->dy_img_mul == 0 || d->dy_mode == OCT_IN_S2D, "oct_conv_wgrad: the dY image map belongs to S2D");
   OCT_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->c0 > 0 && d->c1 >= 0 && d->cout > 0, "oct_conv_wgrad: bad shape");
   OCT_CHECK(a->x0 && a->dy && a->dwp, "oct_conv_wgrad: null tensor");
   OCT_CHECK(d->c1 == 0 || a->x1, "oct_conv_wgrad: c1 > 0 but x1 is null");
@@ -205,7 +212,7 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   OCT_CHECK(!(d->xform0 && (!a->scale0 || !a->shift0)), "oct_conv_wgrad: xform0 without scale/shift");
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
   if (kh != 7) {
-    int took = oct_first_wgrad(d, a, stream);
+    int took = d->depth > 0 ? 0 : oct_first_wgrad(d, a, stream);
     if (took == 0 && a->dy_coef) OCT_CHECK(false, "oct_conv_wgrad: the fused BN-backward apply is only implemented for the 1->F first layer in bf16");
     if (took == 0) took = oct_conv_wgrad_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
@@ -215,6 +222,7 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   p.dy = a->dy; p.dwp = a->dwp; p.dbias = a->dbias;
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.ktot = d->c0 + d->c1; p.cout = d->cout;
   p.xf0 = d->xform0; p.xf1 = d->xform1; p.dy_mode = d->dy_mode;
+  p.depth = d->depth; p.img_shift = d->in_img_shift; p.dy_mul = d->dy_img_mul; p.dy_add = d->dy_img_add;
   p.tiles_x = ceil_div(d->w, 32); p.tiles_y = ceil_div(d->h, 8); p.ntiles = p.tiles_x * p.tiles_y * d->n;
   const int nco = ceil_div(d->cout, 32), nci = ceil_div(p.ktot, 32);
   // persistent workgroups: ~4 per CU over all channel-block pairs
@@ -319,6 +327,34 @@ extern "C" int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cou
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), mode, dwp, grad, cout, cin,
                      accumulate, total, 9);
   return oct_check_launch("unpack_wgrad");
+}
+
+// 3-D unpacking (see oct_hip.h)
+__global__ void unpack_wgrad3d_kernel(int mode, const float* __restrict__ dwp, float* __restrict__ grad, int cout, int cin,
+                                      int kdi, int accumulate, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float v; size_t o;
+    if (mode == OCT_PACK_CONV3D_FPROP) {   // i over grad[co][ci][kd][tap]
+      const int tap = i % 9; size_t r = i / 9; const int kd = r % 3; r /= 3; const int ci = r % cin; const int co = r / cin;
+      v = dwp[(((size_t)kd * 9 + tap) * cout + co) * cin + ci];
+      o = i;
+    } else {                               // i over (ci, co, dydx) of depth slice kdi: grad[ci][co][kdi][dydx]
+      const int dydx = i & 3; const size_t r = i >> 2; const int co = r % cout; const int ci = r / cout;
+      v = dwp[((size_t)dydx * cout + co) * cin + ci];
+      o = (((size_t)ci * cout + co) * 2 + kdi) * 4 + dydx;
+    }
+    grad[o] = accumulate ? grad[o] + v : v;
+  }
+}
+extern "C" int oct_unpack_wgrad3d(int mode, const float* dwp, float* grad, int cout, int cin, int kdi, int accumulate,
+                                  void* stream) {
+  OCT_CHECK(mode == OCT_PACK_CONV3D_FPROP || mode == OCT_PACK_DECONV3D_FPROP, "oct_unpack_wgrad3d: bad mode %d", mode);
+  OCT_CHECK(dwp && grad && cout > 0 && cin > 0 && (kdi == 0 || (kdi == 1 && mode == OCT_PACK_DECONV3D_FPROP)), "oct_unpack_wgrad3d: bad arguments");
+  const size_t total = (size_t)cout * cin * (mode == OCT_PACK_CONV3D_FPROP ? 27 : 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(unpack_wgrad3d_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), mode, dwp, grad, cout, cin, kdi,
+                     accumulate, total);
+  return oct_check_launch("unpack_wgrad3d");
 }
 
 // dwp[kh*kw][cout][cin] -> grad (Cout, Cin, kh, kw) for any kernel size (ReLayNet's 7x3)

@@ -375,6 +375,7 @@ static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
 // returns 1 when taken, 0 when the shape is not eligible, <0 on error
 int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
   if (!w2_enabled()) return 0;
+  if (d->depth > 0 || d->dy_img_mul != 0 || d->kh == 7) return 0;   // depth taps / 7x3: generic kernel
   const int ktot = d->c0 + d->c1;
   // plain 3x3 / 1x1: any H, W (ragged last tiles are predicated); the deconv mode needs whole tiles
   const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;

@@ -187,7 +187,7 @@ class UNetEngine:
     def _act(self, n, h, w, c, dev):
         return torch.empty((n, h, w, c), dtype=self.tdt, device=dev)
 
-    def _pack(self, key: str, wt: torch.Tensor, mode: int, cout: int, cin: int) -> torch.Tensor:
+    def _pack(self, key: str, wt: torch.Tensor, mode: int, cout: int, cin: int, kdi: int = 0) -> torch.Tensor:
         # packed copies are reused until the parameter changes: torch bumps _version on in-place
         # updates, our own raw-pointer optimizer bumps L.param_generation
         ver = (wt._version, L.param_generation[0])
@@ -198,11 +198,18 @@ class UNetEngine:
         rows, taps, kch = {
             L.PACK_CONV_FPROP: (cout, 9, cin), L.PACK_CONV_DGRAD: (cin, 9, cout),
             L.PACK_DECONV_FPROP: (4 * cout, 1, cin), L.PACK_DECONV_DGRAD: (cin, 1, 4 * cout),
-            L.PACK_1X1_DGRAD: (cin, 1, cout), L.PACK_1X1_FPROP: (cout, 1, cin)}[mode]
+            L.PACK_1X1_DGRAD: (cin, 1, cout), L.PACK_1X1_FPROP: (cout, 1, cin),
+            L.PACK_CONV3D_FPROP: (cout, 9, 3 * cin), L.PACK_CONV3D_DGRAD: (cin, 9, 3 * cout),
+            L.PACK_DECONV3D_FPROP: (4 * cout, 1, cin), L.PACK_DECONV3D_DGRAD: (cin, 1, 8 * cout)}[mode]
         elems = L.lib().oct_packed_weight_elems(rows, taps, kch)
         out = hit[1] if hit is not None else torch.empty(elems, dtype=self.tdt, device=wt.device)
-        L.check(L.lib().oct_pack_weights(mode, self.dt, wt.data_ptr(), out.data_ptr(), cout, cin, _stream()),
-                "oct_pack_weights")
+        if mode >= L.PACK_CONV3D_FPROP:
+            self._pack_plan.pop((key, mode), None)      # the batched re-pack launch knows the 2-D modes only
+            L.check(L.lib().oct_pack_weights3d(mode, self.dt, wt.data_ptr(), out.data_ptr(), cout, cin, kdi, _stream()),
+                    "oct_pack_weights3d")
+        else:
+            L.check(L.lib().oct_pack_weights(mode, self.dt, wt.data_ptr(), out.data_ptr(), cout, cin, _stream()),
+                    "oct_pack_weights")
         self._packed[(key, mode)] = (ver, out, wt.data_ptr())
         return out
 
@@ -225,12 +232,13 @@ class UNetEngine:
             self._packed.update(news)
 
     def _conv(self, src: Src, wpacked, cout, taps, n, h, w, y0, *, y1=None, split=0, in_mode=L.IN_PLAIN,
-              out_mode=L.OUT_PLAIN, bias=None, stats=None, kh=0, kw=0):
-        """taps 9 / 1 = 3x3 / 1x1; any other kernel passes (kh, kw) and taps = kh*kw (7x3: ReLayNet)."""
+              out_mode=L.OUT_PLAIN, bias=None, stats=None, kh=0, kw=0, depth=0, oimg=(0, 0)):
+        """taps 9 / 1 = 3x3 / 1x1; any other kernel passes (kh, kw) and taps = kh*kw (7x3: ReLayNet).
+        depth = D > 0: the n images are volumes of D slices and the GEMM gains depth taps (oct_hip.h, OctConvDesc)."""
         d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                        L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE,
-                       in_mode, out_mode, split, 1 if stats is not None else 0, kh, kw)
+                       in_mode, out_mode, split, 1 if stats is not None else 0, kh, kw, depth, oimg[0], oimg[1])
         a = L.ConvArgs(L.ptr(src.x0), L.ptr(src.x1),
                        L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                        L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
@@ -239,20 +247,25 @@ class UNetEngine:
         L.check(L.lib().oct_conv_forward(C.byref(d), C.byref(a), _stream()), "oct_conv_forward")
         self._prof_end(ev, "igemm")
 
-    def _stat_blocks(self, cout, n, h, w, src: Src, taps=9, kh=0, kw=0):
+    def _stat_blocks(self, cout, n, h, w, src: Src, taps=9, kh=0, kw=0, depth=0):
         """rows of the partial-statistics buffer the conv with this exact descriptor will write"""
         d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                        L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
-                       L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, 0, 0, 0, 1, kh, kw)
+                       L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, 0, 0, 0, 1, kh, kw, depth, 0, 0)
         return L.lib().oct_conv_stat_blocks(C.byref(d))
 
-    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None, fused_apply=None, kh=0, kw=0):
-        """fused_apply = (y, coef, scale, shift): `dy` holds dA and the kernel applies BN backward on load."""
+    def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None, fused_apply=None, kh=0, kw=0,
+               depth=0, in_shift=0, dy_img=(0, 0), dwp=None):
+        """fused_apply = (y, coef, scale, shift): `dy` holds dA and the kernel applies BN backward on load.
+        depth / in_shift / dy_img: one depth tap of a 3-D weight gradient (oct_hip.h, OctWgradDesc); dwp: write into this
+        (zeroed) slab instead of taking a new one."""
         ktot = src.channels
-        dwp = self._dwp_take(taps * cout * ktot, dy.device).view(taps, cout, ktot)
+        if dwp is None:
+            dwp = self._dwp_take(taps * cout * ktot, dy.device).view(taps, cout, ktot)
         d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                         L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
-                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, dy_mode, kh, kw)
+                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, dy_mode, kh, kw, depth, in_shift,
+                        dy_img[0], dy_img[1])
         a = L.WgradArgs(L.ptr(src.x0), L.ptr(src.x1),
                         L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                         L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,

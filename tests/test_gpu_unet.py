@@ -118,7 +118,7 @@ def rel_l2(got, ref):
     return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
 
 
-def bf16_against_rounding_aware_oracle(model, state, x, t, w_ce, w_dice, eps, tag, grad_tol=(0.35, 0.12)):
+def bf16_against_rounding_aware_oracle(model, state, x, t, w_ce, w_dice, eps, tag, grad_tol=(0.4, 0.25)):
     """bf16 HIP step vs oracle/ref_cpu.OracleUNet(storage="bf16", dtype=float32): the same network with a bf16
     rounding at every point where the HIP path stores bf16, accumulating in fp32 like the MFMA does.  Forward
     quantities (probabilities, arg-max, loss) agree tightly.  Gradients of a FREE-RUNNING comparison cannot: a
