@@ -85,6 +85,11 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercise the multi-rank plumbing on CPU tensors")
     ap.add_argument("--bucket-mb", type=float, default=3.0, help="gradient bucket threshold (MB)")
+    ap.add_argument("--config", default="cfg2", choices=("cfg2", "cfg4", "cfg5"),
+                    help="cfg2 (default, the headline line the driver runs): Layers_Segment UNet(1,8) 512x1024 batch 32; "
+                         "cfg4: attention-gated AttU_Net(1,3) 496x768 batch 16; cfg5: volumetric UNet3D 64x512x512 batch 4 "
+                         "(BASELINE configs[3] / [4]; single GPU; --batch/--height/--width/--depth shrink them)")
+    ap.add_argument("--depth", type=int, default=64, help="cfg5: slices per volume")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+loss+backward as one HIP graph (no gain at batch 32: the queue never runs dry)")
     return ap.parse_args(argv)
@@ -233,6 +238,127 @@ def traffic_from_profile(args, launches):
     return round(total / max(launches, 1)), f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, csrc {doc['csrc_digest']})"
 
 
+def attunet_train_flops(h, w, in_ch=1, classes=3, ch=(64, 128, 256, 512, 1024)):
+    """Algorithmic conv FLOPs of one B-scan's AttU_Net training step (SD_Layer_Net/unet.py:76-150, common.py:6-91):
+    2*MAC of every Conv2d, x3 for fwd + dgrad + wgrad, minus the data gradient of the very first conv (SURVEY App. A rule)."""
+    def c3(hh, ww, ci, co):
+        return 2.0 * hh * ww * 9 * ci * co
+
+    def c1(hh, ww, ci, co):
+        return 2.0 * hh * ww * ci * co
+    fwd, hh, ww, ci = 0.0, h, w, in_ch
+    sizes = []
+    for lvl, co in enumerate(ch):                      # conv_block: init_conv + two convs
+        if lvl:
+            hh //= 2
+            ww //= 2
+        fwd += c3(hh, ww, ci, co) + 2 * c3(hh, ww, co, co)
+        sizes.append((hh, ww))
+        ci = co
+    first = c3(h, w, in_ch, ch[0])
+    for lvl in range(len(ch) - 1, 0, -1):              # Up (bilinear + conv3x3), Att (three 1x1), Up_conv (conv_block on the concat)
+        hh, ww = sizes[lvl - 1]
+        co, fint = ch[lvl - 1], ch[lvl - 1] // 2
+        fwd += c3(hh, ww, ch[lvl], co)
+        fwd += 2 * c1(hh, ww, co, fint) + c1(hh, ww, fint, 1)
+        fwd += c3(hh, ww, 2 * co, co) + 2 * c3(hh, ww, co, co)
+    fwd += c1(h, w, ch[0], classes)
+    return 3.0 * fwd - first
+
+
+def unet3d_train_flops(features, classes, d, h, w, in_ch=1):
+    """The same rule for the volumetric U-Net (27 taps per Conv3d, 8 per ConvTranspose3d)."""
+    f = features
+    fwd = 0.0
+    first = 2.0 * d * h * w * 27 * in_ch * f
+    vox, cin = d * h * w, in_ch
+    for lvl in range(4):
+        c = f << lvl
+        fwd += 2.0 * vox * 27 * (cin * c + c * c)
+        cin = c
+        vox //= 8
+    fwd += 2.0 * vox * 27 * (cin * 16 * f + 16 * f * 16 * f)
+    c = 16 * f
+    for lvl in range(4):
+        fwd += 2.0 * vox * c * (c // 2) * 8
+        vox *= 8
+        c //= 2
+        fwd += 2.0 * vox * 27 * (2 * c * c + c * c)
+    fwd += 2.0 * vox * f * classes
+    return 3.0 * fwd - first
+
+
+def side_config(args) -> int:
+    """cfg4 / cfg5 (BASELINE configs[3] / [4]): single GPU, same JSON contract; not the line the driver parses."""
+    import torch
+    import torch.nn.functional as F
+    from retinal_oct_image_segmentation_via_deep_learning_amd.optim import FusedSGD
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234)
+    if args.config == "cfg4":
+        from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Lesions_Segment.SD_Layer_Net import AttU_Net
+        b = args.batch if args.batch != 32 else 16
+        h, w = (args.height, args.width) if (args.height, args.width) != (512, 1024) else (496, 768)
+        model = AttU_Net(1, 3).to(dev).train()
+        x = torch.randn(b, 1, h, w, generator=g).to(dev)
+        t = torch.randint(0, 3, (b, h, w), generator=g).to(dev)
+        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+        flops = attunet_train_flops(h, w)
+        unit, workload = "B-scans/s", f"SOTAS AttU_Net(1,3) (SD_Layer_Net/unet.py:76-150) train step, {h}x{w}, batch {b} (BASELINE configs[3])"
+        step_desc = "fwd + torch cross_entropy on the logits + bwd (autograd over the HIP ops layer) + torch SGD(momentum)"
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(model(x), t)
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        from retinal_oct_image_segmentation_via_deep_learning_amd.unet3d import UNet3D
+        b = args.batch if args.batch != 32 else 4
+        d = args.depth
+        h, w = (args.height, args.width) if (args.height, args.width) != (512, 1024) else (512, 512)
+        model = UNet3D(1, args.classes if args.classes != 8 else 4, init_features=args.features).to(dev).train()
+        ncls = model.conv.out_channels
+        x = torch.randn(b, 1, d, h, w, generator=g).to(dev)
+        t = torch.randint(0, ncls, (b, d, h, w), generator=g).to(dev)
+        opt = FusedSGD(list(model.named_parameters()), lr=0.01, momentum=0.9)
+        flops = unet3d_train_flops(args.features, ncls, d, h, w)
+        unit, workload = "volumes/s", (f"UNet3D(1,{ncls},init_features={args.features}) train step, {d}x{h}x{w}, batch {b} "
+                                      f"(BASELINE configs[4]; no reference counterpart)")
+        step_desc = "fwd + CE loss + bwd + fused SGD(momentum), all on liboct_hip.so"
+
+        def step():
+            loss = model.forward_backward(x, t)
+            opt.step()
+            return loss[0]
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    value = b * args.steps / elapsed
+    achieved = value * flops / 1e12
+    print(json.dumps({
+        "metric": f"{unit[:-2]}/sec (train fwd+bwd), {args.config}", "value": round(value, 3), "unit": unit, "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": workload, "global_batch": b, "parallelism": "dp1", "step": step_desc + "; inputs resident in HBM"},
+        "loss": float(loss),
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "kernel": "whole step (algorithmic conv FLOPs of the network / step time)",
+                     "flop_per_unit": flops},
+        "cpu_baseline": None,
+        "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+    return 0
+
+
 def worker(args) -> int:
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
@@ -244,6 +370,11 @@ def worker(args) -> int:
     import torch.distributed as dist
     from retinal_oct_image_segmentation_via_deep_learning_amd import UNet, ddp
 
+    if args.config != "cfg2":
+        if args.gpus != 1 or args.dry_run:
+            print("bench.py: --config cfg4 / cfg5 are single-GPU lines", file=sys.stderr)
+            return 2
+        return side_config(args)
     backend = "gloo" if args.dry_run and args.backend == "nccl" and not torch.cuda.is_available() else args.backend
     rank, world, local = ddp.init_from_env(backend)
     if args.dry_run:

@@ -26,6 +26,9 @@ struct Igemm2Params {
   int n, h, w, c0, c1, cout, split, xf0, xf1, in_mode, out_mode;
   int tiles_x, tiles_y, nblk, nitems, per_wg, nch, nk16;
   int interleave;   // 1: workgroup b walks tiles b, b + grid, b + 2*grid, ... (all channel blocks of a tile), 0: a contiguous item range
+  // 3-D (see OctConvDesc.depth): nchc = 32-channel chunks per depth tap; chunk ch = kd*nchc + c reads slice d + kd - 1.
+  // S2D with depth: k = (kd, dy, dx, c) gathers from slice 2d + kd.  D2S: output image = img*oimg_mul + oimg_add.
+  int depth, nchc, oimg_mul, oimg_add;
   unsigned long long* trace;  // diagnostic builds only (-DOCT_TRACE): s_memtime stamps of workgroup 0
 };
 
@@ -178,16 +181,30 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       }
       const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
                             (txi == p.tiles_x - 1 ? 8u : 0u);
-      const size_t origin = ((size_t)img * p.h + tyi * TH) * p.w + txi * TW;
-      const bool second = !s2d && ch * 32 >= p.c0;  // uniform: a 32-channel chunk lies in one source
+      // depth taps (3-D): chunk ch = kd * nchc + chc reads slice d + kd - 1 of the same volume; a slice outside the
+      // volume is all padding -- its loads re-read the tile's own slice (valid memory) and every slot is dead
+      int chc = ch, srcimg = img;
+      bool zok = true;
+      if (!s2d && p.depth > 0) {
+        const int kdi = ch / p.nchc;
+        chc = ch - kdi * p.nchc;
+        const int dz = img % p.depth + kdi - 1;
+        zok = dz >= 0 && dz < p.depth;
+        srcimg = zok ? img + kdi - 1 : img;
+      }
+      const size_t origin = ((size_t)srcimg * p.h + tyi * TH) * p.w + txi * TW;
+      const bool second = !s2d && chc * 32 >= p.c0;  // uniform: a 32-channel chunk lies in one source
       const int cs = second ? p.c1 : p.c0;
       const bf16_t* base;
-      if (s2d) {  // k = (dy*2+dx)*C + c of the 2H x 2W tensor
-        const int dydx = (ch * 32) / p.c0, cc = ch * 32 - dydx * p.c0;
-        const size_t o2 = ((size_t)img * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
+      if (s2d) {  // k = (dy*2+dx)*C + c of the 2H x 2W tensor (3-D: k = (kd,dy,dx,c), slice 2d + kd)
+        int dydx = (ch * 32) / p.c0;
+        const int cc = ch * 32 - dydx * p.c0;
+        int img2 = img;
+        if (p.depth > 0) { img2 = 2 * img + (dydx >> 2); dydx &= 3; }
+        const size_t o2 = ((size_t)img2 * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
         base = p.x0 + o2 * p.c0 + cc + grp * 8;
       } else {
-        base = (second ? p.x1 + origin * p.c1 + (ch * 32 - p.c0) : p.x0 + origin * p.c0 + ch * 32) + grp * 8;
+        base = (second ? p.x1 + origin * p.c1 + (chc * 32 - p.c0) : p.x0 + origin * p.c0 + chc * 32) + grp * 8;
       }
       // Loads are UNCONDITIONAL (out-of-image / dead slots re-read the tile origin and are zeroed at
       // commit): a load under a divergent branch makes hipcc fall back to s_waitcnt vmcnt(0) at every
@@ -199,7 +216,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       vm = 0;
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
-        const bool ok = (code[i] & edge) == 0;
+        const bool ok = zok && (code[i] & edge) == 0;
         Rr[i] = *reinterpret_cast<const u32x4*>(hb + (ok ? __umul24((unsigned)relp[i], cs2) : safe));
         vm |= ok ? (1u << i) : 0u;
       }
@@ -207,11 +224,12 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     auto commit = [&](unsigned char* buf, const u32x4 (&Rr)[NSLOT], unsigned vm) {
       const int ch = c_ch;
       if (c_sidx < last) { ++c_sidx; if (++c_ch == p.nch) c_ch = 0; }
-      int cg = ch * 32 + grp * 8;
+      const int chc = (!s2d && p.depth > 0) ? ch % p.nchc : ch;   // channel chunk inside its depth tap
+      int cg = chc * 32 + grp * 8;
       if (s2d) cg -= ((ch * 32) / p.c0) * p.c0;
       // wave-uniform on purpose (a 32-channel chunk lies in one source): a per-lane select between the
       // two kernel arguments would become a VECTOR load + s_waitcnt vmcnt(0) in the middle of the ring
-      const bool first = s2d || ch * 32 < p.c0;
+      const bool first = s2d || chc * 32 < p.c0;
       const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
       float s[8], b[8];
       if (xf) {
@@ -359,7 +377,8 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       if (d2s) { cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0; }
       else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
       else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
-      const size_t pix0 = d2s ? ((size_t)img * (2 * p.h) + 2 * oy0 + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * (txi * TW) + (dydx & 1)
+      const int oimg = (d2s && p.oimg_mul) ? img * p.oimg_mul + p.oimg_add : img;
+      const size_t pix0 = d2s ? ((size_t)oimg * (2 * p.h) + 2 * oy0 + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * (txi * TW) + (dydx & 1)
                               : ((size_t)img * p.h + oy0) * p.w + txi * TW;
       e_fb[q] = reinterpret_cast<unsigned char*>(dst + pix0 * cd + co);
       e_rowb[q] = (d2s ? 8u : 2u) * (unsigned)p.w * (unsigned)cd;   // one output row down (two for the deconv scatter)
@@ -732,8 +751,8 @@ static bool v2_enabled() {
 static V2Plan plan_v2(const OctConvDesc* d) {
   V2Plan pl = {};
   if (!v2_enabled()) return pl;
-  if (d->depth > 0 || d->out_img_mul != 0 || d->kh == 7) return pl;   // depth taps / 7x3: generic kernels
-  const int cin = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
+  if (d->kh == 7) return pl;   // 7x3: generic kernels
+  const int cin = d->in_mode == OCT_IN_S2D ? (d->depth > 0 ? 8 : 4) * d->c0 : d->c0 + d->c1;   // channels per depth tap
   // plain 3x3: any H, W (ragged last tiles are predicated); the deconv modes need whole tiles
   const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;
   pl.ok = d->dtype == OCT_DT_BF16 && (whole || d->taps == 9) && (d->c0 % 32) == 0 &&
@@ -746,7 +765,7 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   if (!pl.ok) return pl;
   pl.nt = d->cout == 32 ? 32 : (d->cout % 128 == 0 ? 128 : (d->cout % 64 == 0 ? 64 : 0));
   if (pl.nt == 0) { pl.ok = false; return pl; }
-  pl.wres = (d->taps == 9) && (cin == 32) && (d->cout == pl.nt) && pl.nt <= 64;
+  pl.wres = (d->taps == 9) && (cin == 32) && (d->cout == pl.nt) && pl.nt <= 64 && d->depth == 0;   // 3-D: three chunks per item
   pl.nblk = d->cout / pl.nt;
   // Cout = 32 (full-resolution, HBM-bound layers): 16-row tiles halve the halo overhead per output pixel
   // 16-row tiles: Cout = 32 always; Cout = 64 with streamed weights in fprop (each wave then owns 4 rows x 64
@@ -810,8 +829,9 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
   p.xf0 = d->xform0; p.xf1 = d->xform1;
   p.tiles_x = (d->w + 31) / 32; p.tiles_y = (d->h + pl.th - 1) / pl.th; p.nblk = pl.nblk; p.nitems = pl.nitems; p.per_wg = pl.per_wg;
   p.interleave = pl.interleave;
-  const int ktot = d->in_mode == OCT_IN_S2D ? 4 * d->c0 : d->c0 + d->c1;
+  const int ktot = d->in_mode == OCT_IN_S2D ? (d->depth > 0 ? 8 : 4) * d->c0 : (d->depth > 0 ? 3 : 1) * (d->c0 + d->c1);
   p.nch = ktot / 32; p.nk16 = ktot / 16;
+  p.depth = d->depth; p.nchc = (d->c0 + d->c1) / 32; p.oimg_mul = d->out_img_mul; p.oimg_add = d->out_img_add;
   hipStream_t s = as_stream(stream);
   if (d->taps == 1) {
     if (pl.nt == 32) launch_v2_1x1<4, 1, 2, 1>(p, pl.grid, s);

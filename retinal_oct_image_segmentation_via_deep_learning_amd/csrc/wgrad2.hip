@@ -23,6 +23,8 @@ struct Wgrad2Params {
   int n, h, w, c0, c1, ktot, cout, xf0, xf1, dy_mode;
   int tiles_x, tiles_y, ntiles, per_wg;
   int interleave;   // 1: workgroup x walks tiles x, x + gridDim.x, ... (see igemm2.hip), 0: a contiguous tile range
+  int depth, img_shift;   // 3-D: the input tile comes from slice d + img_shift of the same volume (all zero outside)
+  int dy_mul, dy_add;     // S2D dY gathered from image img*dy_mul + dy_add (0: identity)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -124,17 +126,26 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
                             (txi == p.tiles_x - 1 ? 8u : 0u);
       const size_t origin = ((size_t)img * p.h + tyi * TH) * p.w + txi * TW;
+      // 3-D: the input tile of this depth tap lies one slice up / down; outside the volume it is padding (the loads
+      // then re-read the tile's own slice and every slot is marked dead)
+      bool zok = true;
+      size_t in_origin = origin;
+      if (p.depth > 0) {
+        const int dz = img % p.depth + p.img_shift;
+        zok = dz >= 0 && dz < p.depth;
+        if (zok) in_origin = ((size_t)(img + p.img_shift) * p.h + tyi * TH) * p.w + txi * TW;
+      }
 #pragma unroll
       for (int blk = 0; blk < IB; ++blk) {
         const int cg = ci_sb + blk * 32;
         const bool second = cg >= p.c0;
         const int cs = second ? p.c1 : p.c0;
-        const bf16_t* base = (second ? p.x1 + origin * p.c1 + (cg - p.c0) : p.x0 + origin * p.c0 + cg) + g * 8;
+        const bf16_t* base = (second ? p.x1 + in_origin * p.c1 + (cg - p.c0) : p.x0 + in_origin * p.c0 + cg) + g * 8;
         // unconditional loads (see igemm2.hip): invalid slots re-read the tile origin, zeroed at commit
         unsigned vm = 0;
 #pragma unroll
         for (int j = 0; j < SIB; ++j) {
-          const bool ok = (code[j] & edge) == 0;
+          const bool ok = zok && (code[j] & edge) == 0;
           S.ri[blk][j] = *reinterpret_cast<const u32x4*>(base + (ok ? __mul24(reli[j], cs) : 0));
           vm |= ok ? (1u << j) : 0u;
         }
@@ -148,7 +159,8 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         if (p.dy_mode == OCT_IN_S2D) {
           cs = p.cout >> 2;
           const int dydx = row / cs, co = row - dydx * cs;
-          const size_t o2 = ((size_t)img * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
+          const int img2 = p.dy_mul ? img * p.dy_mul + p.dy_add : img;
+          const size_t o2 = ((size_t)img2 * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
           base = p.dy + o2 * cs + co + g * 8;
         } else {
           cs = p.cout;
@@ -375,7 +387,7 @@ static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
 // returns 1 when taken, 0 when the shape is not eligible, <0 on error
 int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
   if (!w2_enabled()) return 0;
-  if (d->depth > 0 || d->dy_img_mul != 0 || d->kh == 7) return 0;   // depth taps / 7x3: generic kernel
+  if (d->kh == 7) return 0;   // 7x3: generic kernel
   const int ktot = d->c0 + d->c1;
   // plain 3x3 / 1x1: any H, W (ragged last tiles are predicated); the deconv mode needs whole tiles
   const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;
@@ -389,6 +401,7 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
   p.dy = (const bf16_t*)a->dy; p.dwp = a->dwp; p.dbias = a->dbias;
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.ktot = ktot; p.cout = d->cout;
   p.xf0 = d->xform0; p.xf1 = d->xform1; p.dy_mode = d->dy_mode;
+  p.depth = d->depth; p.img_shift = d->in_img_shift; p.dy_mul = d->dy_img_mul; p.dy_add = d->dy_img_add;
   const int nco = d->cout / 32, nci = ktot / 32;
   const bool big = (nco % 2 == 0) && (nci % 2 == 0);
   hipStream_t s = as_stream(stream);
