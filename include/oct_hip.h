@@ -153,6 +153,12 @@ typedef struct OctWgradDesc {
   int in_img_shift;  /* -1, 0, +1 = kd - 1 (Conv3d); 0 otherwise                                                       */
   int dy_img_mul, dy_img_add; /* dy_mode S2D only, 0,0 = identity: dY is gathered from image img*mul + add
                       * (ConvTranspose3d weight gradient: two launches, mul = 2, add = kd)                               */
+  int partials;      /* 0: partial sums of the workgroups meet in dwp through fp32 atomics (dwp zeroed by the caller; the
+                      * summation order, hence the last bits, vary from run to run).  1: DETERMINISTIC two-stage reduction --
+                      * every workgroup writes its partial sums with plain stores into its own slab of
+                      * dwp[oct_conv_wgrad_partials(desc)][taps][cout][ktot] (nothing to zero), and the unpack pass
+                      * (OctUnpackJob.nparts) adds the slabs in index order.  Same for the bias gradient through
+                      * OctWgradArgs.dbias_partials + oct_reduce_bias_partials.                                          */
 } OctWgradDesc;
 typedef struct OctWgradArgs {
   const void* x0; const void* x1;
@@ -164,8 +170,15 @@ typedef struct OctWgradArgs {
   /* optional fused BatchNorm-backward apply (first layer only, OCT_E_INVALID elsewhere): when dy_coef != NULL,
    * `dy` holds dA and the kernel forms dy = coef0*[y*scale+shift>0]*dA + coef1*y + coef2 on the fly */
   const void* dy_y; const float* dy_coef; const float* dy_scale; const float* dy_shift;
+  float* dbias_partials; /* partials mode with dbias != NULL: [slabs][cout] fp32 (GEMM rows, i.e. 4*Cout for the deconv) */
 } OctWgradArgs;
 int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
+/* slabs a launch of this descriptor writes when partials = 1 (host query, never fails; >= 1) */
+int oct_conv_wgrad_partials(const OctWgradDesc* d);
+/* dbias[c] (+)= sum over slabs, in order, of the `rows / channels` GEMM rows that map to channel c (rows = 4*Cout for the
+ * transposed convolution, else Cout)                                                                     */
+int oct_reduce_bias_partials(const float* part, int nparts, int rows, int channels, float* dbias, int accumulate,
+                             void* stream);
 /* 1 when oct_conv_wgrad accepts dy_coef (fused BatchNorm-backward apply) for this descriptor, else 0: the
  * caller then materialises dY with oct_bn_bwd_apply first.  Host-only query, never fails.               */
 int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d);
@@ -181,6 +194,7 @@ int oct_unpack_wgrad3d(int mode, const float* dwp, float* grad, int cout, int ci
 /* The same for up to OCT_PACK_BATCH_MAX gradients per launch (a whole backward pass).               */
 typedef struct OctUnpackJob {
   int mode, cout, cin, accumulate;
+  int nparts, reserved; /* slabs to sum in order (partials mode); 0 or 1: dwp is a single accumulated buffer */
   const float* dwp;   /* [taps][rows][kch] fp32 from oct_conv_wgrad (device) */
   float* grad;        /* torch-layout fp32 gradient (device) */
 } OctUnpackJob;

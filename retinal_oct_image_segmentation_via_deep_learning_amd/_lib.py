@@ -34,8 +34,8 @@ class PackJob(C.Structure):          # struct OctPackJob
 
 
 class UnpackJob(C.Structure):        # struct OctUnpackJob
-    _fields_ = [("mode", c_int), ("cout", c_int), ("cin", c_int), ("accumulate", c_int), ("dwp", c_void_p),
-                ("grad", c_void_p)]
+    _fields_ = [("mode", c_int), ("cout", c_int), ("cin", c_int), ("accumulate", c_int), ("nparts", c_int),
+                ("reserved", c_int), ("dwp", c_void_p), ("grad", c_void_p)]
 
 
 PACK_BATCH_MAX = 96
@@ -55,12 +55,12 @@ class ConvArgs(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [(k, c_int) for k in (
         "dtype", "n", "h", "w", "c0", "c1", "cout", "taps", "xform0", "xform1", "dy_mode", "kh", "kw", "depth",
-        "in_img_shift", "dy_img_mul", "dy_img_add")]
+        "in_img_shift", "dy_img_mul", "dy_img_add", "partials")]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [(k, c_void_p) for k in ("x0", "x1", "scale0", "shift0", "scale1", "shift1", "dy", "dwp", "dbias",
-                                                "dy_y", "dy_coef", "dy_scale", "dy_shift")]
+                                                "dy_y", "dy_coef", "dy_scale", "dy_shift", "dbias_partials")]
 
 
 class HeadDesc(C.Structure):
@@ -93,6 +93,8 @@ SIGNATURES = {
     "oct_conv_forward": (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvArgs), c_void_p]),
     "oct_conv_wgrad": (c_int, [C.POINTER(WgradDesc), C.POINTER(WgradArgs), c_void_p]),
     "oct_conv_wgrad_fused_apply_ok": (c_int, [C.POINTER(WgradDesc)]),
+    "oct_conv_wgrad_partials": (c_int, [C.POINTER(WgradDesc)]),
+    "oct_reduce_bias_partials": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "oct_unpack_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "oct_unpack_wgrad_batch": (c_int, [c_int, C.POINTER(UnpackJob), c_void_p]),
     "oct_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,

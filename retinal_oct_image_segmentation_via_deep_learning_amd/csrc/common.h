@@ -26,11 +26,11 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
 int oct_conv_v2_stat_rows(const OctConvDesc* d);
 // igemm.hip: (kh, kw) of a descriptor (0, 0 -> from taps); false for unsupported sizes
 bool oct_conv_kernel_size(int taps, int kh_in, int kw_in, int* kh, int* kw);
-int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
+int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query = nullptr);
 // first.hip: direct kernels for Conv2d(1 -> F)
 int oct_first_stat_rows(const OctConvDesc* d);
 int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream);
-int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream);
+int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query = nullptr);
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }

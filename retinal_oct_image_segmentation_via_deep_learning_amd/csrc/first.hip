@@ -102,11 +102,10 @@ template <int F>
 __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                           float* __restrict__ dwp, int n, int h, int w,
                                                           const bf16_t* __restrict__ yraw, const float* __restrict__ coef,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift) {
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          int part_mode) {
   constexpr int G = F / 8, PPB = 256 / G;
-  __shared__ float sacc[9 * F];
-  for (int i = threadIdx.x; i < 9 * F; i += 256) sacc[i] = 0.f;
-  __syncthreads();
+  __shared__ float sacc[4][9 * F];   // one row per wave: summed in wave order, so the block result does not depend on timing
   float acc[9][8];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -169,10 +168,14 @@ __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restri
       float v = acc[t][j];
 #pragma unroll
       for (int o = 32; o >= G; o >>= 1) v += __shfl_xor(v, o);
-      if ((threadIdx.x & 63) < G) atomicAdd(&sacc[t * F + g * 8 + j], v);
+      if ((threadIdx.x & 63) < G) sacc[threadIdx.x >> 6][t * F + g * 8 + j] = v;   // lanes < G hold distinct channel groups
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < 9 * F; i += 256) atomicAdd(&dwp[i], sacc[i]);  // dwp[tap][co][ci = 0]
+  for (int i = threadIdx.x; i < 9 * F; i += 256) {   // dwp[tap][co][ci = 0]
+    const float v = (sacc[0][i] + sacc[1][i]) + (sacc[2][i] + sacc[3][i]);
+    if (part_mode) dwp[(size_t)blockIdx.x * 9 * F + i] = v;   // partials mode: slab per workgroup, summed in order by the unpack pass
+    else atomicAdd(&dwp[i], v);
+  }
 }
 
 static bool f1_enabled() {
@@ -217,17 +220,19 @@ extern "C" int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d) {
   return (size_t)d->n * d->h * d->w < (1u << 31) ? 1 : 0;
 }
 
-int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
+int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query) {
   if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
-  if (a->dy_coef && (!a->dy_y || !a->dy_scale || !a->dy_shift)) { oct_set_error("oct_conv_wgrad: fused apply needs y, scale, shift"); return OCT_E_INVALID; }
+  if (!query && a->dy_coef && (!a->dy_y || !a->dy_scale || !a->dy_shift)) { oct_set_error("oct_conv_wgrad: fused apply needs y, scale, shift"); return OCT_E_INVALID; }
   const size_t total = (size_t)d->n * d->h * d->w * (d->cout / 8);
   if ((size_t)d->n * d->h * d->w >= (1u << 31)) return 0;   // 32-bit pixel arithmetic in the kernel
   size_t b = (total + 255) / 256;
   if (b > 512) b = 512;   // two workgroups per CU: 0.54 ms against 0.62 at 4096 (fprop, write-dominated, prefers 2048-4096)
+  if (query) { *query = (int)b; return 1; }
+  const int part_mode = d->partials ? 1 : 0;
   hipStream_t s = as_stream(stream);
 #define LAUNCH(F) hipLaunchKernelGGL(first_wgrad_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
                                      (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
-                                     (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift)
+                                     (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode)
   if (d->cout == 16) LAUNCH(16); else if (d->cout == 32) LAUNCH(32); else LAUNCH(64);
 #undef LAUNCH
   int rc = oct_check_launch("first_wgrad");

@@ -58,7 +58,10 @@ __device__ __forceinline__ float bf16hi(unsigned u) { return __uint_as_float(u &
 
 // RAGGED: H or W is not a multiple of the tile; whole-tile shapes (the benchmark) run the instantiation
 // without any of the predication below (measured: 2-3 % when it was unconditional).
-template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS, bool RAGGED = false>
+// D3: the depth taps / image maps of the volumetric network (OctConvDesc.depth, out_img_*).  A template switch, not a
+// runtime one: the same code guarded by `p.depth > 0` inside the producers' issue path cost the 2-D benchmark 12 % of
+// its igemm2 time (measured: 13.7 -> 15.4 ms per step), these kernels being bound by exactly that path.
+template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS, bool RAGGED = false, bool D3 = false>
 __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   static_assert(WM * WN == 4, "four MFMA waves");
   constexpr int TH = WM * MF, TW = 32;
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // volume is all padding -- its loads re-read the tile's own slice (valid memory) and every slot is dead
       int chc = ch, srcimg = img;
       bool zok = true;
-      if (!s2d && p.depth > 0) {
+      if (D3 && !s2d) {
         const int kdi = ch / p.nchc;
         chc = ch - kdi * p.nchc;
         const int dz = img % p.depth + kdi - 1;
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         int dydx = (ch * 32) / p.c0;
         const int cc = ch * 32 - dydx * p.c0;
         int img2 = img;
-        if (p.depth > 0) { img2 = 2 * img + (dydx >> 2); dydx &= 3; }
+        if (D3) { img2 = 2 * img + (dydx >> 2); dydx &= 3; }
         const size_t o2 = ((size_t)img2 * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
         base = p.x0 + o2 * p.c0 + cc + grp * 8;
       } else {
@@ -216,7 +219,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       vm = 0;
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
-        const bool ok = zok && (code[i] & edge) == 0;
+        const bool ok = (!D3 || zok) && (code[i] & edge) == 0;
         Rr[i] = *reinterpret_cast<const u32x4*>(hb + (ok ? __umul24((unsigned)relp[i], cs2) : safe));
         vm |= ok ? (1u << i) : 0u;
       }
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     auto commit = [&](unsigned char* buf, const u32x4 (&Rr)[NSLOT], unsigned vm) {
       const int ch = c_ch;
       if (c_sidx < last) { ++c_sidx; if (++c_ch == p.nch) c_ch = 0; }
-      const int chc = (!s2d && p.depth > 0) ? ch % p.nchc : ch;   // channel chunk inside its depth tap
+      const int chc = (D3 && !s2d) ? ch % p.nchc : ch;   // channel chunk inside its depth tap
       int cg = chc * 32 + grp * 8;
       if (s2d) cg -= ((ch * 32) / p.c0) * p.c0;
       // wave-uniform on purpose (a 32-channel chunk lies in one source): a per-lane select between the
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       if (d2s) { cd = p.cout >> 2; dydx = cb0 / cd; co = cb0 - dydx * cd; dst = p.y0; }
       else if (p.split > 0 && cb0 >= p.split) { dst = p.y1; cd = p.cout - p.split; co = cb0 - p.split; }
       else { dst = p.y0; cd = p.split > 0 ? p.split : p.cout; co = cb0; }
-      const int oimg = (d2s && p.oimg_mul) ? img * p.oimg_mul + p.oimg_add : img;
+      const int oimg = (D3 && d2s) ? img * p.oimg_mul + p.oimg_add : img;
       const size_t pix0 = d2s ? ((size_t)oimg * (2 * p.h) + 2 * oy0 + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * (txi * TW) + (dydx & 1)
                               : ((size_t)img * p.h + oy0) * p.w + txi * TW;
       e_fb[q] = reinterpret_cast<unsigned char*>(dst + pix0 * cd + co);
@@ -752,6 +755,7 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   V2Plan pl = {};
   if (!v2_enabled()) return pl;
   if (d->kh == 7) return pl;   // 7x3: generic kernels
+  if ((d->depth > 0 || d->out_img_mul != 0) && ((d->w % 32) != 0 || (d->h % 16) != 0)) return pl;   // volumetric: whole tiles
   const int cin = d->in_mode == OCT_IN_S2D ? (d->depth > 0 ? 8 : 4) * d->c0 : d->c0 + d->c1;   // channels per depth tap
   // plain 3x3: any H, W (ragged last tiles are predicated); the deconv modes need whole tiles
   const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;
@@ -797,7 +801,12 @@ static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float) +
                   (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
   const bool ragged = (p.w % 32) != 0 || (p.h % TH) != 0;
-  if (ragged) {
+  if (p.depth > 0) {   // volumetric: whole tiles only (plan_v2), streamed weights
+    if constexpr (!WRES) {
+      if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, false, true, false, true>), dim3(grid), dim3(512), lds, s, p);
+      else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, false, false, false, true>), dim3(grid), dim3(512), lds, s, p);
+    }
+  } else if (ragged) {
     if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true, true>), dim3(grid), dim3(512), lds, s, p);
     else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false, true>), dim3(grid), dim3(512), lds, s, p);
   } else if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(512), lds, s, p);
@@ -807,7 +816,10 @@ template <int WM, int WN, int MF, int NF>
 static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
   const int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float);
-  hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(512), lds, s, p);
+  if (p.depth > 0 || p.oimg_mul)
+    hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false, false, true>), dim3(grid), dim3(512), lds, s, p);
+  else
+    hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(512), lds, s, p);
 }
 
 // returns 1 when the launch was taken by this path, 0 when the shape is not eligible, <0 on error
@@ -832,6 +844,7 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
   const int ktot = d->in_mode == OCT_IN_S2D ? (d->depth > 0 ? 8 : 4) * d->c0 : (d->depth > 0 ? 3 : 1) * (d->c0 + d->c1);
   p.nch = ktot / 32; p.nk16 = ktot / 16;
   p.depth = d->depth; p.nchc = (d->c0 + d->c1) / 32; p.oimg_mul = d->out_img_mul; p.oimg_add = d->out_img_add;
+  if (p.depth > 0 && p.oimg_mul == 0) p.oimg_mul = 1;   // the D3 instantiation always applies the image map
   hipStream_t s = as_stream(stream);
   if (d->taps == 1) {
     if (pl.nt == 32) launch_v2_1x1<4, 1, 2, 1>(p, pl.grid, s);

@@ -23,6 +23,7 @@ struct WgradParams {
   int ty0, pad_h, pad_w;   // first kernel row this launch covers, "same" padding of the whole kernel
   int depth, img_shift;    // 3-D: the input tile comes from slice d + img_shift of the same volume (zero outside)
   int dy_mul, dy_add;      // S2D dY: gathered from image img*dy_mul + dy_add (0: identity)
+  int part_mode; size_t slab_elems; float* dbias_part;   // partials mode, see wgrad2.hip: slab = (blockIdx.x, wave)
 };
 
 template <typename T>
@@ -176,10 +177,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       }
     }
   }
+  const int slab = blockIdx.x * 4 + wave;
   if (p.dbias && blockIdx.z == 0) {
     bsum += __shfl_xor(bsum, 32);
     const int cr = (p.dy_mode == OCT_IN_S2D) ? (p.cout >> 2) : p.cout;
-    if (hh == 0 && co0 + r < p.cout) atomicAdd(&p.dbias[(co0 + r) % cr], bsum);
+    if (hh == 0 && co0 + r < p.cout) {
+      if (p.part_mode) p.dbias_part[(size_t)slab * p.cout + co0 + r] = bsum;
+      else atomicAdd(&p.dbias[(co0 + r) % cr], bsum);
+    }
   }
   // D[row = co][col = ci]: reg i -> co = co0 + (i&3) + 8*(i>>2) + 4*hh ; lane -> ci = ci0 + r
   const int ci = ci0 + r;
@@ -189,7 +194,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (co < p.cout) atomicAdd(&p.dwp[((size_t)(p.ty0 * KW + t) * p.cout + co) * p.ktot + ci], acc[t][i]);
+        if (co < p.cout) {
+          float* const q = &p.dwp[(p.part_mode ? (size_t)slab * p.slab_elems : 0) + ((size_t)(p.ty0 * KW + t) * p.cout + co) * p.ktot + ci];
+          if (p.part_mode) *q = acc[t][i]; else atomicAdd(q, acc[t][i]);
+        }
       }
   }
 }
@@ -211,6 +219,7 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   OCT_CHECK(!(d->dy_mode == OCT_IN_S2D && (d->cout & 3)), "oct_conv_wgrad: S2D dy needs cout %% 4 == 0");
   OCT_CHECK(!(d->xform0 && (!a->scale0 || !a->shift0)), "oct_conv_wgrad: xform0 without scale/shift");
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
+  OCT_CHECK(!d->partials || !a->dbias || a->dbias_partials, "oct_conv_wgrad: partials mode with a bias gradient needs dbias_partials");
   if (kh != 7) {
     int took = d->depth > 0 ? 0 : oct_first_wgrad(d, a, stream);
     if (took == 0 && a->dy_coef) OCT_CHECK(false, "oct_conv_wgrad: the fused BN-backward apply is only implemented for the 1->F first layer in bf16");
@@ -230,6 +239,7 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   if (per_pair < 1) per_pair = 1;
   if (per_pair > p.ntiles) per_pair = p.ntiles;
   dim3 grid(per_pair, nco, nci);
+  p.part_mode = d->partials ? 1 : 0; p.slab_elems = (size_t)d->taps * d->cout * p.ktot; p.dbias_part = a->dbias_partials;
   const int esz = d->dtype == OCT_DT_BF16 ? 2 : 4;
   const int pixe = 32 + 8 / esz * 2;
   p.pad_h = (kh - 1) / 2; p.pad_w = (kw - 1) / 2;
@@ -261,22 +271,62 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   return oct_check_launch("wgrad");
 }
 
-// dwp[tap][rows][kch] -> torch-layout gradient
+// Number of partial slabs a launch with this descriptor writes in partials mode (OctWgradDesc.partials = 1): the caller
+// sizes dwp as [slabs][taps][cout][ktot] (and dbias_partials as [slabs][cout]) and hands `slabs` to the unpack pass.
+extern "C" int oct_conv_wgrad_partials(const OctWgradDesc* d) {
+  if (!d) return 0;
+  int kh = 0, kw = 0;
+  if (!oct_conv_kernel_size(d->taps, d->kh, d->kw, &kh, &kw)) return 0;
+  int q = 0;
+  if (kh != 7) {
+    if (d->depth == 0 && oct_first_wgrad(d, nullptr, nullptr, &q) == 1) return q;
+    if (oct_conv_wgrad_v2(d, nullptr, nullptr, &q) == 1) return q;
+  }
+  const int ktot = d->c0 + d->c1;
+  const int nco = ceil_div(d->cout, 32), nci = ceil_div(ktot, 32);
+  const int ntiles = ceil_div(d->w, 32) * ceil_div(d->h, 8) * d->n;
+  int per_pair = 1024 / (nco * nci);
+  if (per_pair < 1) per_pair = 1;
+  if (per_pair > ntiles) per_pair = ntiles;
+  return per_pair * 4;
+}
+
+// dwp[slab][tap][rows][kch] -> torch-layout gradient; the slabs (1 for the atomics mode) are summed in index order
 __global__ void unpack_wgrad_kernel(int mode, const float* __restrict__ dwp, float* __restrict__ grad, int cout,
-                                    int cin, int accumulate, size_t total, int taps) {
+                                    int cin, int accumulate, size_t total, int taps, int nparts, size_t slab) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    float v;
+    size_t o;
     if (mode == OCT_PACK_CONV_FPROP) {  // grad[co][ci][tap]
       const int tap = i % taps; const size_t r = i / taps; const int ci = r % cin; const int co = r / cin;
-      v = dwp[((size_t)tap * cout + co) * cin + ci];
+      o = ((size_t)tap * cout + co) * cin + ci;
     } else if (mode == OCT_PACK_DECONV_FPROP) {  // grad[ci][co][dydx] ; dwp[0][dydx*cout+co][ci]
       const int dydx = i & 3; const size_t r = i >> 2; const int co = r % cout; const int ci = r / cout;
-      v = dwp[((size_t)dydx * cout + co) * cin + ci];
+      o = ((size_t)dydx * cout + co) * cin + ci;
     } else {  // 1x1: grad[co][ci] = dwp[0][co][ci]
-      v = dwp[i];
+      o = i;
     }
+    float v = dwp[o];
+    for (int g = 1; g < nparts; ++g) v += dwp[(size_t)g * slab + o];
     grad[i] = accumulate ? grad[i] + v : v;
   }
+}
+
+// bias gradient of partials mode: dbias[c] (+)= sum over slabs (in order) and over the `fold` GEMM rows that share channel c
+__global__ void reduce_bias_partials_kernel(const float* __restrict__ part, int nparts, int rows, int cr, float* __restrict__ dbias,
+                                            int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cr) return;
+  float v = 0.f;
+  for (int g = 0; g < nparts; ++g)
+    for (int q = c; q < rows; q += cr) v += part[(size_t)g * rows + q];
+  dbias[c] = accumulate ? dbias[c] + v : v;
+}
+extern "C" int oct_reduce_bias_partials(const float* part, int nparts, int rows, int channels, float* dbias, int accumulate,
+                                        void* stream) {
+  OCT_CHECK(part && dbias && nparts > 0 && rows > 0 && channels > 0 && rows % channels == 0, "oct_reduce_bias_partials: bad arguments");
+  hipLaunchKernelGGL(reduce_bias_partials_kernel, dim3(ceil_div(channels, 256)), dim3(256), 0, as_stream(stream), part, nparts,
+                     rows, channels, dbias, accumulate);
+  return oct_check_launch("reduce_bias_partials");
 }
 
 // every unpacking of a backward pass in one launch (22 five-microsecond launches otherwise)
@@ -287,17 +337,20 @@ __global__ void unpack_wgrad_batch_kernel(const UnpackJobs jobs) {
   const float* __restrict__ dwp = jb.dwp;
   float* __restrict__ grad = jb.grad;
   const size_t total = (size_t)cout * cin * (mode == OCT_PACK_CONV_FPROP ? 9 : mode == OCT_PACK_DECONV_FPROP ? 4 : 1);
+  const int nparts = jb.nparts > 1 ? jb.nparts : 1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    float v;
+    size_t o;
     if (mode == OCT_PACK_CONV_FPROP) {
       const int tap = i % 9; const size_t r = i / 9; const int ci = r % cin; const int co = r / cin;
-      v = dwp[((size_t)tap * cout + co) * cin + ci];
+      o = ((size_t)tap * cout + co) * cin + ci;
     } else if (mode == OCT_PACK_DECONV_FPROP) {
       const int dydx = i & 3; const size_t r = i >> 2; const int co = r % cout; const int ci = r / cout;
-      v = dwp[((size_t)dydx * cout + co) * cin + ci];
+      o = ((size_t)dydx * cout + co) * cin + ci;
     } else {
-      v = dwp[i];
+      o = i;
     }
+    float v = dwp[o];
+    for (int g = 1; g < nparts; ++g) v += dwp[(size_t)g * total + o];   // slab size == total for these modes
     grad[i] = jb.accumulate ? grad[i] + v : v;
   }
 }
@@ -325,7 +378,7 @@ extern "C" int oct_unpack_wgrad(int mode, const float* dwp, float* grad, int cou
   const size_t total = (size_t)cout * cin * (mode == OCT_PACK_CONV_FPROP ? 9 : mode == OCT_PACK_DECONV_FPROP ? 4 : 1);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), mode, dwp, grad, cout, cin,
-                     accumulate, total, 9);
+                     accumulate, total, 9, 1, (size_t)0);
   return oct_check_launch("unpack_wgrad");
 }
 
@@ -364,6 +417,6 @@ extern "C" int oct_unpack_wgrad_kk(const float* dwp, float* grad, int cout, int 
   const size_t total = (size_t)cout * cin * kh * kw;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), OCT_PACK_CONV_FPROP, dwp, grad,
-                     cout, cin, accumulate, total, kh * kw);
+                     cout, cin, accumulate, total, kh * kw, 1, (size_t)0);
   return oct_check_launch("unpack_wgrad_kk");
 }

@@ -25,6 +25,10 @@ struct Wgrad2Params {
   int interleave;   // 1: workgroup x walks tiles x, x + gridDim.x, ... (see igemm2.hip), 0: a contiguous tile range
   int depth, img_shift;   // 3-D: the input tile comes from slice d + img_shift of the same volume (all zero outside)
   int dy_mul, dy_add;     // S2D dY gathered from image img*dy_mul + dy_add (0: identity)
+  // partials mode (OctWgradDesc.partials): every (workgroup column, row strip) writes its accumulators with plain stores
+  // into its own slab dwp[slab][tap][cout][ktot] (and dbias_part[slab][cout]); oct_unpack_wgrad sums the slabs in order.
+  // No atomics: the result does not depend on scheduling, and nothing has to be zeroed.
+  int part_mode; size_t slab_elems; float* dbias_part;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -48,7 +52,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TAPS, int CB, int IB, int TH, bool RAGGED>
+// D3: depth shift of the input tile / image map of an S2D dY (volumetric network) -- compile-time, see igemm2.hip
+template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false>
 __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   constexpr int TW = 32;
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -130,7 +135,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       // then re-read the tile's own slice and every slot is marked dead)
       bool zok = true;
       size_t in_origin = origin;
-      if (p.depth > 0) {
+      if (D3 && p.depth > 0) {
         const int dz = img % p.depth + p.img_shift;
         zok = dz >= 0 && dz < p.depth;
         if (zok) in_origin = ((size_t)(img + p.img_shift) * p.h + tyi * TH) * p.w + txi * TW;
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         unsigned vm = 0;
 #pragma unroll
         for (int j = 0; j < SIB; ++j) {
-          const bool ok = zok && (code[j] & edge) == 0;
+          const bool ok = (!D3 || zok) && (code[j] & edge) == 0;
           S.ri[blk][j] = *reinterpret_cast<const u32x4*>(base + (ok ? __mul24(reli[j], cs) : 0));
           vm |= ok ? (1u << j) : 0u;
         }
@@ -159,7 +164,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         if (p.dy_mode == OCT_IN_S2D) {
           cs = p.cout >> 2;
           const int dydx = row / cs, co = row - dydx * cs;
-          const int img2 = p.dy_mul ? img * p.dy_mul + p.dy_add : img;
+          const int img2 = (D3 && p.dy_mul) ? img * p.dy_mul + p.dy_add : img;
           const size_t o2 = ((size_t)img2 * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
           base = p.dy + o2 * cs + co + g * 8;
         } else {
@@ -333,19 +338,23 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   // D[row = co][col = ci]
   const int r = lane & 31, hh = lane >> 5;
   const int ci = ci_sb + ib * 32 + r;
+  const int slab = blockIdx.x * PS + psx;
+  float* const out = p.dwp + (p.part_mode ? (size_t)slab * p.slab_elems : 0);
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = co_sb + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      atomicAdd(&p.dwp[((size_t)t * p.cout + co) * p.ktot + ci], acc[t][i]);
+      float* const q = &out[((size_t)t * p.cout + co) * p.ktot + ci];
+      if (p.part_mode) *q = acc[t][i]; else atomicAdd(q, acc[t][i]);
     }
   if (do_bias && r == 0) {
     const int cr = (p.dy_mode == OCT_IN_S2D) ? (p.cout >> 2) : p.cout;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = co_sb + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      atomicAdd(&p.dbias[co % cr], accb[i]);
+      if (p.part_mode) p.dbias_part[(size_t)slab * p.cout + co] = accb[i];
+      else atomicAdd(&p.dbias[co % cr], accb[i]);
     }
   }
 }
@@ -356,14 +365,14 @@ static bool w2_enabled() {
   return on == 1;
 }
 
-template <int TAPS, int CB, int IB, int TH, bool RAGGED>
+template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false>
 static void launch_w2r(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   constexpr int halo = TAPS == 9 ? 1 : 0;
   constexpr int stage = IB * (TH + 2 * halo) * (32 + 2 * halo) * 64 + CB * TH * 32 * 64;
   constexpr int lds = 2 * stage + 2 * 32 * IB * (int)sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<TAPS, CB, IB, TH, RAGGED>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<TAPS, CB, IB, TH, RAGGED, D3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
@@ -375,19 +384,24 @@ static void launch_w2r(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   p.per_wg = (p.ntiles + gx - 1) / gx;
   p.interleave = p.ntiles >= 2 * gx ? 1 : 0;
   if (!p.interleave) gx = (p.ntiles + p.per_wg - 1) / p.per_wg;
-  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH, RAGGED>), dim3(gx, gy, gz), dim3(512), lds, s, p);
+  if (p.part_mode < 0) { p.part_mode = gx * (4 / (CB * IB)); return; }   // query: slabs this launch would write
+  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH, RAGGED, D3>), dim3(gx, gy, gz), dim3(512), lds, s, p);
 }
 template <int TAPS, int CB, int IB, int TH>
 static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   // whole tiles take the instantiation without the dY validity mask (no register cost on the bench shapes)
-  if ((p.w % 32) == 0 && (p.h % TH) == 0) launch_w2r<TAPS, CB, IB, TH, false>(p, nco, nci, s);
+  const bool whole = (p.w % 32) == 0 && (p.h % TH) == 0;
+  if (p.depth > 0 || p.dy_mul) launch_w2r<TAPS, CB, IB, TH, false, true>(p, nco, nci, s);   // volumetric: whole tiles (checked by the caller)
+  else if (whole) launch_w2r<TAPS, CB, IB, TH, false>(p, nco, nci, s);
   else launch_w2r<TAPS, CB, IB, TH, true>(p, nco, nci, s);
 }
 
-// returns 1 when taken, 0 when the shape is not eligible, <0 on error
-int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream) {
+// returns 1 when taken, 0 when the shape is not eligible, <0 on error; query != nullptr: no launch, *query = number
+// of partial slabs the launch would write in partials mode
+int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query) {
   if (!w2_enabled()) return 0;
   if (d->kh == 7) return 0;   // 7x3: generic kernel
+  if ((d->depth > 0 || d->dy_img_mul != 0) && ((d->w % 32) != 0 || (d->h % 16) != 0)) return 0;   // volumetric: whole tiles
   const int ktot = d->c0 + d->c1;
   // plain 3x3 / 1x1: any H, W (ragged last tiles are predicated); the deconv mode needs whole tiles
   const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;
@@ -396,9 +410,14 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
                   (d->dy_mode == OCT_IN_PLAIN || ((d->cout >> 2) % 32) == 0);
   if (!ok) return 0;
   Wgrad2Params p;
+  static const OctWgradArgs no_args = {};
+  if (query) a = &no_args;
   p.x0 = (const bf16_t*)a->x0; p.x1 = (const bf16_t*)a->x1;
   p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
   p.dy = (const bf16_t*)a->dy; p.dwp = a->dwp; p.dbias = a->dbias;
+  p.part_mode = query ? -1 : (d->partials ? 1 : 0);
+  p.slab_elems = (size_t)d->taps * d->cout * ktot; p.dbias_part = a->dbias_partials;
+  if (p.part_mode == 1 && a->dbias && !a->dbias_partials) { oct_set_error("oct_conv_wgrad: partials mode with a bias gradient needs dbias_partials"); return OCT_E_INVALID; }
   p.n = d->n; p.h = d->h; p.w = d->w; p.c0 = d->c0; p.c1 = d->c1; p.ktot = ktot; p.cout = d->cout;
   p.xf0 = d->xform0; p.xf1 = d->xform1; p.dy_mode = d->dy_mode;
   p.depth = d->depth; p.img_shift = d->in_img_shift; p.dy_mul = d->dy_img_mul; p.dy_add = d->dy_img_add;
@@ -413,6 +432,7 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
   } else {
     if (big) launch_w2<1, 2, 2, 8>(p, nco, nci, s); else launch_w2<1, 1, 1, 8>(p, nco, nci, s);   // 8 rows: -14 % vs 4
   }
+  if (query) { *query = p.part_mode; return 1; }
   int rc = oct_check_launch("wgrad2");
   return rc ? rc : 1;
 }

@@ -18,6 +18,7 @@ Data layout in HBM
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -158,6 +159,9 @@ class UNetEngine:
         self._packed = {}  # (key, mode) -> (version, tensor)
         self._arena, self._arena_on, self._arena_off, self._arena_short = None, False, 0, False
         self._unpack_jobs = []
+        # deterministic = True: weight gradients through the two-stage reduction (OctWgradDesc.partials: per-workgroup slabs
+        # summed in order) instead of fp32 atomics -- bit-identical gradients from run to run (OCT_DETERMINISTIC=1 sets it)
+        self.deterministic = os.environ.get("OCT_DETERMINISTIC", "0") == "1"
         self.debug = None  # set to a dict to capture intermediate gradients (tests / probes)
         self.prof = None   # set to a list: (kind, start_event, end_event) around every MFMA launch
 
@@ -260,20 +264,32 @@ class UNetEngine:
         depth / in_shift / dy_img: one depth tap of a 3-D weight gradient (oct_hip.h, OctWgradDesc); dwp: write into this
         (zeroed) slab instead of taking a new one."""
         ktot = src.channels
-        if dwp is None:
-            dwp = self._dwp_take(taps * cout * ktot, dy.device).view(taps, cout, ktot)
+        parts = 1 if (self.deterministic and dwp is None and depth == 0) else 0
         d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                         L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
                         L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, dy_mode, kh, kw, depth, in_shift,
-                        dy_img[0], dy_img[1])
+                        dy_img[0], dy_img[1], parts)
+        bias_parts = None
+        if parts:
+            nparts = L.lib().oct_conv_wgrad_partials(C.byref(d))
+            dwp = torch.empty((nparts, taps, cout, ktot), dtype=torch.float32, device=dy.device)   # every slab is written whole
+            dwp._oct_nparts = nparts
+            if dbias is not None:
+                bias_parts = torch.empty((nparts, cout), dtype=torch.float32, device=dy.device)
+        elif dwp is None:
+            dwp = self._dwp_take(taps * cout * ktot, dy.device).view(taps, cout, ktot)
         a = L.WgradArgs(L.ptr(src.x0), L.ptr(src.x1),
                         L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
                         L.ptr(src.bn1.scale) if src.bn1 else None, L.ptr(src.bn1.shift) if src.bn1 else None,
                         L.ptr(dy), L.ptr(dwp), L.ptr(dbias), *([L.ptr(t) for t in fused_apply] if fused_apply
-                                                                 else [None, None, None, None]))
+                                                                 else [None, None, None, None]), L.ptr(bias_parts))
         ev = self._prof_begin()
         L.check(L.lib().oct_conv_wgrad(C.byref(d), C.byref(a), _stream()), "oct_conv_wgrad")
         self._prof_end(ev, "wgrad")
+        if bias_parts is not None:     # the caller zeroed dbias (atomics contract): add the ordered sum to it
+            L.check(L.lib().oct_reduce_bias_partials(bias_parts.data_ptr(), nparts, cout,
+                                                     cout // 4 if dy_mode == L.IN_S2D else cout, dbias.data_ptr(), 1,
+                                                     _stream()), "oct_reduce_bias_partials")
         return dwp
 
     def _dwp_take(self, numel: int, dev) -> torch.Tensor:
@@ -307,11 +323,12 @@ class UNetEngine:
         self._arena_on = False
 
     def _unpack(self, mode, dwp, grad, cout, cin, accumulate):
+        job = L.UnpackJob(mode, cout, cin, int(accumulate), getattr(dwp, "_oct_nparts", 1), 0, dwp.data_ptr(), grad.data_ptr())
         if self._arena_on:   # inside backward(): all gradients are unpacked by one launch at the end
-            self._unpack_jobs.append((L.UnpackJob(mode, cout, cin, int(accumulate), dwp.data_ptr(), grad.data_ptr()), dwp, grad))
+            self._unpack_jobs.append((job, dwp, grad))
             return
-        L.check(L.lib().oct_unpack_wgrad(mode, dwp.data_ptr(), grad.data_ptr(), cout, cin, int(accumulate),
-                                         _stream()), "oct_unpack_wgrad")
+        arr = (L.UnpackJob * 1)(job)
+        L.check(L.lib().oct_unpack_wgrad_batch(1, arr, _stream()), "oct_unpack_wgrad_batch")
 
     # ---- forward --------------------------------------------------------------------------------
     def _conv_bn(self, P, keys: ConvKeys, src: Src, cout, n, h, w, train: bool) -> ConvRec:

@@ -460,3 +460,37 @@ def test_headline_width_bf16_layers_teacher_forced_against_oracle(golden_dir):
         u = ulps(dx, R.round_bf16(dx_ref))
         # (a heavily cancelling sum can sit several bf16 ulps of its own small value away from the fp32 accumulation)
         assert (u > 0).mean() < 1e-2 and (u > 1.01).mean() < 1e-4 and u.max() < 64, (wk, "dgrad", (u > 0).mean(), u.max())
+
+
+@pytest.mark.parametrize("dtype,shape", [("bf16", (2, 128, 256)), ("f32", (2, 32, 64))])
+def test_deterministic_weight_gradients_are_bit_reproducible(dtype, shape):
+    """engine.deterministic (OctWgradDesc.partials): per-workgroup partial slabs summed in index order instead of fp32
+    atomics.  Two runs give bit-identical convolution / transposed-convolution weight and bias gradients; against the
+    atomics mode they differ by fp32 round-off only.  (The 1x1 head's 8 x 32 weights and its bias still meet through
+    atomics inside the fused head kernel and are not part of the bit-equality claim.)"""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import UNet
+    torch.manual_seed(5)
+    model = UNet(1, 8, init_features=32, compute_dtype=dtype).cuda().train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    b, h, w = shape
+    x = torch.randn(b, 1, h, w, generator=g).cuda()
+    t = torch.randint(0, 8, (b, h, w), generator=g).cuda()
+
+    def grads(det):
+        model.load_state_dict(state)
+        model._engine.deterministic = det
+        model.forward_backward(x, t)
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    a, b2, c = grads(True), grads(True), grads(False)
+    model._engine.deterministic = False
+    conv_keys = [k for k in a if ("conv" in k and k.endswith("weight") and not k.startswith("conv.")) or k.startswith("upconv")]
+    assert len(conv_keys) == 18 + 8
+    for k in conv_keys:
+        assert torch.equal(a[k], b2[k]), f"{k}: deterministic mode is not reproducible"
+        ref = c[k].double()
+        assert float((a[k].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12, k
+    for k in a:     # everything, loosely: the two modes compute the same gradients
+        ref = c[k].double()
+        assert float((a[k].double() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-9, k
