@@ -366,7 +366,9 @@ extern "C" int oct_unpack_wgrad_batch(int count, const OctUnpackJob* jobs, void*
       OCT_CHECK((m == OCT_PACK_CONV_FPROP || m == OCT_PACK_DECONV_FPROP || m == OCT_PACK_1X1_FPROP) && uj.j[i].dwp &&
                 uj.j[i].grad && uj.j[i].cout > 0 && uj.j[i].cin > 0, "oct_unpack_wgrad_batch: bad job %d", base + i);
     }
-    hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(64, n), dim3(256), 0, as_stream(stream), uj);
+    int gx = 64;   // partial-slab jobs read nparts x as much: spread them over the whole chip
+    for (int i = 0; i < n; ++i) if (uj.j[i].nparts > 1) gx = 1024;
+    hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), uj);
   }
   return oct_check_launch("unpack_wgrad_batch");
 }

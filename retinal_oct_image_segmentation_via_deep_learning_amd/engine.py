@@ -159,6 +159,7 @@ class UNetEngine:
         self._packed = {}  # (key, mode) -> (version, tensor)
         self._arena, self._arena_on, self._arena_off, self._arena_short = None, False, 0, False
         self._unpack_jobs = []
+        self._nbt = []
         # deterministic = True: weight gradients through the two-stage reduction (OctWgradDesc.partials: per-workgroup slabs
         # summed in order) instead of fp32 atomics -- bit-identical gradients from run to run (OCT_DETERMINISTIC=1 sets it)
         self.deterministic = os.environ.get("OCT_DETERMINISTIC", "0") == "1"
@@ -351,7 +352,7 @@ class UNetEngine:
                 P[nk + ".bias"].data_ptr(), BN_EPS, BN_MOMENTUM, P[nk + ".running_mean"].data_ptr(),
                 P[nk + ".running_var"].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                 shift.data_ptr(), cbias, _stream()), "oct_bn_finalize")
-            P[nk + ".num_batches_tracked"].add_(1)
+            self._nbt.append(P[nk + ".num_batches_tracked"])   # bumped by ONE multi-tensor launch at the end of forward
             bn = BNState(scale, shift, mean, invstd)
         else:
             self._conv(src, wp, cout, 9, n, h, w, y)
@@ -392,6 +393,7 @@ class UNetEngine:
         if train:
             self._prepack(P)
         ctx = Ctx(n=n, h=h, w=w, loss_cfg=tuple(loss_cfg))
+        self._nbt = []
         xt = self._act(n, h, w, self.cin, dev)
         L.check(lib.oct_nchw_to_nhwc(self.dt, xf.data_ptr(), xt.data_ptr(), n, self.cin, h, w, _stream()),
                 "oct_nchw_to_nhwc")
@@ -424,6 +426,9 @@ class UNetEngine:
                    else Src(sk.y, sk.cout, sk.bn, u, cout_d, None))
             prev = self._block(P, blk, src, n, hh, ww, train, ctx)
         ctx.head_in = prev
+        if self._nbt:       # BatchNorm step counters: one multi-tensor launch instead of one per layer
+            torch._foreach_add_(self._nbt, 1)
+            self._nbt = []
         hd = L.HeadDesc(self.dt, n, h, w, self.f, self.ncls)
         probs = torch.empty((n, self.ncls, h, w), dtype=torch.float32, device=dev) if want_probs else None
         amax = torch.empty((n, h, w), dtype=torch.int64, device=dev) if want_argmax else None

@@ -48,7 +48,7 @@ class UNet3DEngine(UNetEngine):
                 P[nk + ".bias"].data_ptr(), BN_EPS, BN_MOMENTUM, P[nk + ".running_mean"].data_ptr(),
                 P[nk + ".running_var"].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                 shift.data_ptr(), None, _stream()), "oct_bn_finalize")
-            P[nk + ".num_batches_tracked"].add_(1)
+            self._nbt.append(P[nk + ".num_batches_tracked"])   # bumped by ONE multi-tensor launch at the end of forward
             bn = BNState(scale, shift, mean, invstd)
         else:
             self._conv(src, wp, cout, 9, n, h, w, y, depth=depth)
@@ -85,6 +85,7 @@ class UNet3DEngine(UNetEngine):
         ctx = Ctx(n=b, h=dd * h, w=w, loss_cfg=tuple(loss_cfg))      # head geometry: (B, D*H, W) == (B, D, H, W) flattened
         ctx.vol = (b, dd, h, w)
         ctx.pool2 = {}
+        self._nbt = []
         n = b * dd
         xt = self._act(n, h, w, self.cin, dev)
         L.check(lib.oct_nchw_to_nhwc(self.dt, xf.data_ptr(), xt.data_ptr(), b, self.cin, dd * h, w, _stream()), "oct_nchw_to_nhwc")
@@ -123,6 +124,9 @@ class UNet3DEngine(UNetEngine):
             src = Src(u, cout_d, None, sk.y, sk.cout, sk.bn)       # cat((dec, enc), 1)
             prev = self._block3(P, blk, src, b * dl, hh, ww, dl, train, ctx)
         ctx.head_in = prev
+        if self._nbt:       # BatchNorm step counters: one multi-tensor launch instead of one per layer
+            torch._foreach_add_(self._nbt, 1)
+            self._nbt = []
         hd = L.HeadDesc(self.dt, b, dd * h, w, self.f, self.ncls)
         probs = torch.empty((b, self.ncls, dd, h, w), dtype=torch.float32, device=dev) if want_probs else None
         amax = torch.empty((b, dd, h, w), dtype=torch.int64, device=dev) if want_argmax else None
