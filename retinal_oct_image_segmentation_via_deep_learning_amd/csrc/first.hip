@@ -32,6 +32,80 @@ __device__ __forceinline__ void f1_taps(const bf16_t* __restrict__ x, unsigned q
   }
 }
 
+// the same neighbourhood one slice up / down (volumes of `depth` slices, n = N*D images): zero outside the volume
+__device__ __forceinline__ void f1_taps_z(const bf16_t* __restrict__ x, unsigned q, int h, int w, int depth, int shift,
+                                          float (&v)[9]) {
+  const unsigned plane = (unsigned)h * (unsigned)w;
+  const int dz = (int)((q / plane) % (unsigned)depth) + shift;
+  const bool zok = dz >= 0 && dz < depth;
+  const unsigned qz = zok ? q + shift * (int)plane : q;
+  f1_taps(x, qz, h, w, v);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) v[t] = zok ? v[t] : 0.f;
+}
+
+// Conv3d(1 -> F, 3x3x3) of the volumetric U-Net's first layer: the same mapping with the 27 x 8 filter taps of the
+// group in registers (216 VGPRs: one wave per SIMD -- the kernel is bound by its 16-B stores, not by occupancy)
+template <int F>
+__global__ void __launch_bounds__(256) first_fprop3d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                            bf16_t* __restrict__ y, float* __restrict__ stats, int n,
+                                                            int h, int w, int depth) {
+  // wp: OCT_PACK_CONV3D_FPROP of the (F,1,3,3,3) filter (kch = 3, nk16 = 1): A[row = co][k = kd] of tap (kh,kw) sits at
+  // ((co/32 * 9 + tap) * 512 + (co%32) * 8 + kd)
+  constexpr int G = F / 8, PPB = 256 / G;
+  __shared__ float red[4][2][F];
+  const int g = threadIdx.x % G, slot = threadIdx.x / G;
+  float wv[27][8];
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int co = g * 8 + j;
+        wv[kd * 9 + t][j] = (float)wp[((co >> 5) * 9 + t) * 512 + (co & 31) * 8 + kd];
+      }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const unsigned npix = (unsigned)n * h * w, stride = gridDim.x * PPB;
+  for (unsigned pix = blockIdx.x * PPB + slot; pix < npix; pix += stride) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      float v[9];
+      f1_taps_z(x, pix, h, w, depth, kd - 1, v);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv[kd * 9 + t][j], v[t], acc[j]);
+    }
+    const u32x4 o = {f1_pack(acc[0], acc[1]), f1_pack(acc[2], acc[3]), f1_pack(acc[4], acc[5]), f1_pack(acc[6], acc[7])};
+    *reinterpret_cast<u32x4*>(y + (size_t)pix * F + g * 8) = o;
+    if (stats) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
+    }
+  }
+  if (stats) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = s1[j], b = s2[j];
+#pragma unroll
+      for (int o = 32; o >= G; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if (lane < G) { red[wave][0][g * 8 + j] = a; red[wave][1][g * 8 + j] = b; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * F; i += 256) {
+      const int st = i / F, c = i % F;
+      stats[((size_t)blockIdx.x * 2 + st) * F + c] = red[0][st][c] + red[1][st][c] + red[2][st][c] + red[3][st][c];
+    }
+  }
+}
+
 // fprop: a thread owns (pixel, 8-channel group): its 72 filter taps stay in registers for the whole
 // kernel, consecutive lanes store consecutive 16-B chunks (1 KB per wave instruction), the taps of
 // the next pixel are loaded while the current one is computed.
@@ -98,12 +172,14 @@ __global__ void __launch_bounds__(256) first_fprop_kernel(const bf16_t* __restri
 // wgrad: the same (pixel, 8-channel group) mapping, 72 register accumulators, one LDS + atomic
 // reduction per workgroup; dY (and y for the fused BN-backward apply) of the next pixel are in flight
 // while the current one is accumulated.
-template <int F>
+// Z3: one depth tap of the Conv3d(1 -> F) weight gradient -- the input taps come from slice d + zshift (compile-time switch:
+// the 2-D kernel keeps its instruction stream)
+template <int F, bool Z3 = false>
 __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                           float* __restrict__ dwp, int n, int h, int w,
                                                           const bf16_t* __restrict__ yraw, const float* __restrict__ coef,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          int part_mode) {
+                                                          int part_mode, int depth = 0, int zshift = 0) {
   constexpr int G = F / 8, PPB = 256 / G;
   __shared__ float sacc[4][9 * F];   // one row per wave: summed in wave order, so the block result does not depend on timing
   float acc[9][8];
@@ -130,7 +206,7 @@ __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restri
     const unsigned q = pix < npix ? pix : 0u;
     dn = *reinterpret_cast<const u32x4*>(dy + (size_t)q * F + g * 8);
     yn = *reinterpret_cast<const u32x4*>(ysrc + (size_t)q * F + g * 8);
-    f1_taps(x, q, h, w, vn);
+    if (Z3) f1_taps_z(x, q, h, w, depth, zshift, vn); else f1_taps(x, q, h, w, vn);
   }
   for (; pix < npix; pix += stride) {
     const u32x4 d = dn, yq = yn;
@@ -141,7 +217,7 @@ __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restri
       const unsigned q = pix + stride < npix ? pix + stride : pix;
       dn = *reinterpret_cast<const u32x4*>(dy + (size_t)q * F + g * 8);
       yn = *reinterpret_cast<const u32x4*>(ysrc + (size_t)q * F + g * 8);
-      f1_taps(x, q, h, w, vn);
+      if (Z3) f1_taps_z(x, q, h, w, depth, zshift, vn); else f1_taps(x, q, h, w, vn);
     }
     float dv[8];
 #pragma unroll
@@ -203,6 +279,15 @@ int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
   const int grid = first_grid(d);
   hipStream_t s = as_stream(stream);
   float* st = d->want_stats ? a->stat_partials : nullptr;
+  if (d->depth > 0) {
+    if ((size_t)d->n * d->h * d->w >= (1ull << 32)) return 0;   // 32-bit voxel arithmetic
+#define LAUNCH3(F) hipLaunchKernelGGL(first_fprop3d_kernel<F>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a->x0, \
+                                      (const bf16_t*)a->wpacked, (bf16_t*)a->y0, st, d->n, d->h, d->w, d->depth)
+    if (d->cout == 16) LAUNCH3(16); else if (d->cout == 32) LAUNCH3(32); else LAUNCH3(64);
+#undef LAUNCH3
+    int rc3 = oct_check_launch("first_fprop3d");
+    return rc3 ? rc3 : 1;
+  }
 #define LAUNCH(F) hipLaunchKernelGGL(first_fprop_kernel<F>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a->x0, \
                                      (const bf16_t*)a->wpacked,                                      (bf16_t*)a->y0, st, d->n, d->h, d->w)
   if (d->cout == 16) LAUNCH(16); else if (d->cout == 32) LAUNCH(32); else LAUNCH(64);
@@ -233,8 +318,13 @@ int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, 
 #define LAUNCH(F) hipLaunchKernelGGL(first_wgrad_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
                                      (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
                                      (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode)
-  if (d->cout == 16) LAUNCH(16); else if (d->cout == 32) LAUNCH(32); else LAUNCH(64);
+#define LAUNCHZ(F) hipLaunchKernelGGL((first_wgrad_kernel<F, true>), dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
+                                      (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
+                                      (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode, d->depth, d->in_img_shift)
+  if (d->depth > 0) { if (d->cout == 16) LAUNCHZ(16); else if (d->cout == 32) LAUNCHZ(32); else LAUNCHZ(64); }
+  else if (d->cout == 16) LAUNCH(16); else if (d->cout == 32) LAUNCH(32); else LAUNCH(64);
 #undef LAUNCH
+#undef LAUNCHZ
   int rc = oct_check_launch("first_wgrad");
   return rc ? rc : 1;
 }

@@ -558,7 +558,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         return ((m + ty) * LW + tx) * PIXB + k16 * 32;
       };
       // ring of LD+1 fragment sets: the reads of step s+LD are in flight while step s multiplies
-      constexpr int LD = (MF * NF >= 8) ? 1 : ((MF * NF >= 4) ? 2 : 3);
+#ifndef IG2_LD8
+#define IG2_LD8 1
+#endif
+      constexpr int LD = (MF * NF >= 8) ? IG2_LD8 : ((MF * NF >= 4) ? 2 : 3);
       Frag xr[LD + 1][MF];
 #pragma unroll
       for (int j = 0; j < LD; ++j)

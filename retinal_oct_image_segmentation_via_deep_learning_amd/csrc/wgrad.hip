@@ -221,7 +221,7 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
   OCT_CHECK(!d->partials || !a->dbias || a->dbias_partials, "oct_conv_wgrad: partials mode with a bias gradient needs dbias_partials");
   if (kh != 7) {
-    int took = d->depth > 0 ? 0 : oct_first_wgrad(d, a, stream);
+    int took = oct_first_wgrad(d, a, stream);
     if (took == 0 && a->dy_coef) OCT_CHECK(false, "oct_conv_wgrad: the fused BN-backward apply is only implemented for the 1->F first layer in bf16");
     if (took == 0) took = oct_conv_wgrad_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
@@ -279,7 +279,7 @@ extern "C" int oct_conv_wgrad_partials(const OctWgradDesc* d) {
   if (!oct_conv_kernel_size(d->taps, d->kh, d->kw, &kh, &kw)) return 0;
   int q = 0;
   if (kh != 7) {
-    if (d->depth == 0 && oct_first_wgrad(d, nullptr, nullptr, &q) == 1) return q;
+    if (oct_first_wgrad(d, nullptr, nullptr, &q) == 1) return q;
     if (oct_conv_wgrad_v2(d, nullptr, nullptr, &q) == 1) return q;
   }
   const int ktot = d->c0 + d->c1;

@@ -29,7 +29,20 @@ struct Wgrad2Params {
   // into its own slab dwp[slab][tap][cout][ktot] (and dbias_part[slab][cout]); oct_unpack_wgrad sums the slabs in order.
   // No atomics: the result does not depend on scheduling, and nothing has to be zeroed.
   int part_mode; size_t slab_elems; float* dbias_part;
+  unsigned long long* trace;   // diagnostic builds only (-DOCT_TRACE): s_memtime stamps of workgroup (0,0,0)
 };
+
+#ifdef OCT_TRACE
+#define W2TRACE(slot, idx)                                                                                     \
+  do {                                                                                                         \
+    if (p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0 && (idx) < 256) \
+      p.trace[(slot) * 256 + (idx)] = __builtin_amdgcn_s_memtime();                                            \
+  } while (0)
+static unsigned long long* g_trace_w2 = nullptr;
+extern "C" void oct_debug_set_trace_w2(void* buf) { g_trace_w2 = (unsigned long long*)buf; }
+#else
+#define W2TRACE(slot, idx) do {} while (0)
+#endif
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -239,9 +252,13 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         const int nx = s0 + j + 1;
+        if (wave == 4) W2TRACE(4, nx - 1);
         commit(smem + (nx & 1) * STAGEB, R[(j + 1) % D]);
+        if (wave == 4) W2TRACE(5, nx - 1);
         issue(min(nx + D, last), R[(j + 1) % D]);
+        if (wave == 4) W2TRACE(6, nx - 1);
         __syncthreads();
+        if (wave == 4) W2TRACE(7, nx - 1);
       }
     }
     return;
@@ -273,6 +290,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   int cur = 0;
   for (int s = 0; s < nstage_pad; ++s) {
     if (s >= nstage) { __syncthreads(); continue; }   // padded stages keep the barrier count in step
+    if (wave == 0) W2TRACE(0, s);
     const unsigned char* in_t = smem + cur * STAGEB + ib * INB + lane_off;
     const unsigned char* dy_t = smem + cur * STAGEB + IB * INB + cb * DYB + lane_off;
     // flattened (row, half, tap) sequence with the transposed reads running two MFMAs ahead
@@ -289,18 +307,24 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       // the four waves asked the LDS for 142 B/clk, more than the 128 B/clk it delivers.
       constexpr int NI = ROWS + 2, NB = NI * 6;
       auto bo = [&](int j) { return ((psx * ROWS + j / 6) * LW + ((j / 3) & 1) * 16 + j % 3) * 64; };
+      // input fragments run LA iterations (up to 3 MFMAs = 96 matrix cycles each) ahead of their use.  LA = 2 left the
+      // reads ~190 cycles of lead, about one loaded-LDS round trip; W2_LA (default 4) doubles it for 8 VGPRs.
+#ifndef W2_LA
+#define W2_LA 2   /* A/B on the box (LA = 2, 4, 6): no difference on any launch -- the kernel is not LDS-latency bound */
+#endif
+      constexpr int LA = W2_LA;
       bf16x8 aw[4][2];
-      bf16x8 bq[3];
+      bf16x8 bq[LA + 1];
       aw[0][0] = tr_frag(dy_t + a_off(0));
       aw[0][1] = tr_frag(dy_t + a_off(1));
-      bq[0] = tr_frag(in_t + bo(0));
-      bq[1] = tr_frag(in_t + bo(1));
+#pragma unroll
+      for (int j = 0; j < LA; ++j) bq[j] = tr_frag(in_t + bo(j));
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int hx = 0; hx < 6; ++hx) {
           const int j = i * 6 + hx, h = hx / 3, tx = hx % 3;
-          if (j + 2 < NB) bq[(j + 2) % 3] = tr_frag(in_t + bo(j + 2));
+          if (j + LA < NB) bq[(j + LA) % (LA + 1)] = tr_frag(in_t + bo(j + LA));
           if (hx == 0 && i + 1 < ROWS) {   // dY of the next output row, a whole input row ahead of its first use
             aw[(i + 1) & 3][0] = tr_frag(dy_t + a_off(2 * (i + 1)));
             aw[(i + 1) & 3][1] = tr_frag(dy_t + a_off(2 * (i + 1) + 1));
@@ -311,7 +335,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
             const int k = i - ty;   // output row that sees input row i through tap row ty
             if (k < 0 || k >= ROWS) continue;
             if (do_bias && ty == 0 && tx == 0) M::mma(accb, aw[k & 3][h], ones);
-            M::mma(acc[ty * 3 + tx], aw[k & 3][h], bq[j % 3]);
+            M::mma(acc[ty * 3 + tx], aw[k & 3][h], bq[j % (LA + 1)]);
           }
         }
     } else {
@@ -331,9 +355,12 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         M::mma(acc[t], aq[k & 1], bq[i % 3]);
       }
     }
+    if (wave == 0) W2TRACE(1, s);
     __syncthreads();
+    if (wave == 0) W2TRACE(2, s);
     cur ^= 1;
   }
+  if (wave == 0) W2TRACE(3, 0);
 
   // D[row = co][col = ci]
   const int r = lane & 31, hh = lane >> 5;
@@ -357,6 +384,10 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       else atomicAdd(&p.dbias[co % cr], accb[i]);
     }
   }
+#ifdef OCT_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wave == 0) W2TRACE(3, 1);
+#endif
 }
 
 static bool w2_enabled() {
@@ -415,6 +446,11 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
   p.x0 = (const bf16_t*)a->x0; p.x1 = (const bf16_t*)a->x1;
   p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
   p.dy = (const bf16_t*)a->dy; p.dwp = a->dwp; p.dbias = a->dbias;
+#ifdef OCT_TRACE
+  p.trace = g_trace_w2;
+#else
+  p.trace = nullptr;
+#endif
   p.part_mode = query ? -1 : (d->partials ? 1 : 0);
   p.slab_elems = (size_t)d->taps * d->cout * ktot; p.dbias_part = a->dbias_partials;
   if (p.part_mode == 1 && a->dbias && !a->dbias_partials) { oct_set_error("oct_conv_wgrad: partials mode with a bias gradient needs dbias_partials"); return OCT_E_INVALID; }
