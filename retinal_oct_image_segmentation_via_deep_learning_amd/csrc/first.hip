@@ -307,6 +307,7 @@ extern "C" int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d) {
 
 int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query) {
   if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
+  if (!query && a->dbias) return 0;   // no bias-gradient path in the direct kernel: the MFMA kernels take it
   if (!query && a->dy_coef && (!a->dy_y || !a->dy_scale || !a->dy_shift)) { oct_set_error("oct_conv_wgrad: fused apply needs y, scale, shift"); return OCT_E_INVALID; }
   const size_t total = (size_t)d->n * d->h * d->w * (d->cout / 8);
   if ((size_t)d->n * d->h * d->w >= (1u << 31)) return 0;   // 32-bit pixel arithmetic in the kernel

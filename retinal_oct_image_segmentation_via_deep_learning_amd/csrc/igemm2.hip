@@ -762,13 +762,17 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   const int cin = d->in_mode == OCT_IN_S2D ? (d->depth > 0 ? 8 : 4) * d->c0 : d->c0 + d->c1;   // channels per depth tap
   // plain 3x3: any H, W (ragged last tiles are predicated); the deconv modes need whole tiles
   const bool whole = (d->w % 32) == 0 && (d->h % 8) == 0;
-  pl.ok = d->dtype == OCT_DT_BF16 && (whole || d->taps == 9) && (d->c0 % 32) == 0 &&
+  // plain -> plain (3x3, and 1x1: the attention gates' W_g / W_x, classifier heads, their data gradients): any H, W;
+  // the deconv modes (1x1 with depth-to-space / space-to-depth addressing) need whole tiles
+  const bool plain = d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN;
+  pl.ok = d->dtype == OCT_DT_BF16 && (whole || plain) && (d->c0 % 32) == 0 &&
           (d->c1 % 32) == 0 && (d->cout % 32) == 0 && (d->split % 32) == 0;
   pl.ok = pl.ok && (d->c0 + d->c1) <= 1024 && d->cout <= 4096;   // LDS tables: 2 x 1024 BN coefficients, 1024 bias values
-  if (d->taps == 9) pl.ok = pl.ok && d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_PLAIN;
-  else pl.ok = pl.ok && !d->want_stats && d->split == 0 &&
-               ((d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_D2S && ((d->cout >> 2) % 32) == 0) ||
-                (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN && d->c1 == 0));
+  if (d->taps == 9) pl.ok = pl.ok && plain;
+  else pl.ok = pl.ok && (plain ||
+               (!d->want_stats && d->split == 0 &&
+                ((d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_D2S && ((d->cout >> 2) % 32) == 0) ||
+                 (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN && d->c1 == 0))));
   if (!pl.ok) return pl;
   pl.nt = d->cout == 32 ? 32 : (d->cout % 128 == 0 ? 128 : (d->cout % 64 == 0 ? 64 : 0));
   if (pl.nt == 0) { pl.ok = false; return pl; }
@@ -818,8 +822,15 @@ static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
 template <int WM, int WN, int MF, int NF>
 static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  const int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float);
-  if (p.depth > 0 || p.oimg_mul)
+  const int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float) +
+                  (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
+  const bool ragged = (p.w % 32) != 0 || (p.h % TH) != 0;
+  if (p.in_mode == OCT_IN_PLAIN && p.out_mode == OCT_OUT_PLAIN && (p.stats || ragged)) {   // plain 1x1 convolution with BN sums / ragged tiles
+    if (ragged) {
+      if (p.stats) hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, true, true>), dim3(grid), dim3(512), lds, s, p);
+      else hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false, true>), dim3(grid), dim3(512), lds, s, p);
+    } else hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, true>), dim3(grid), dim3(512), lds, s, p);
+  } else if (p.depth > 0 || p.oimg_mul)
     hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false, false, true>), dim3(grid), dim3(512), lds, s, p);
   else
     hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(512), lds, s, p);

@@ -178,6 +178,7 @@ class ConvAffineAct(torch.autograd.Function):
         x0, x1, w, y, out, mean, invstd, scale, gamma, shift, alpha = ctx.saved_tensors
         kd = dict(kh=kk[0], kw=kk[1]) if kk else {}
         dalpha = None
+        fuse_bias = False
         e = kernels(dtype)
         lib = L.lib()
         n, h, wd, c0 = x0.shape
@@ -223,12 +224,17 @@ class ConvAffineAct(torch.autograd.Function):
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
         else:
             dy = dz
-            if has_bias:
+            if has_bias and cin % 32 == 0:
+                # bias gradient = sum over pixels of dY: one extra MFMA against a ones fragment inside the weight-gradient
+                # kernel instead of a separate pass over dY (the direct first-layer kernel has no such path: cin = 1, 3 ...)
+                dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
+                fuse_bias = True
+            elif has_bias:
                 dcb = torch.empty(cout, dtype=torch.float32, device=dev)
                 L.check(lib.oct_channel_sum(e.dt, dy.data_ptr(), dcb.data_ptr(), npix, cout, 0, _stream()),
                         "oct_channel_sum")
         src = Src(x0, c0, None, x1, c1, None)
-        dwp = e._wgrad(src, dy, cout, taps, n, h, wd, **kd)
+        dwp = e._wgrad(src, dy, cout, taps, n, h, wd, dbias=dcb if fuse_bias else None, **kd)
         dw = torch.empty_like(w)
         if kk:
             L.check(lib.oct_unpack_wgrad_kk(dwp.data_ptr(), dw.data_ptr(), cout, cin, kk[0], kk[1], 0, _stream()),

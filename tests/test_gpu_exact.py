@@ -241,3 +241,61 @@ def test_first_layer_wgrad_with_fused_bn_backward_bit_exact(env, f):
     assert np.array_equal(to_bf16(dy), dy)
     _, dw = O.conv3x3_bwd(x.astype(np.float64), np.zeros((f, 1, 3, 3)), dy.astype(np.float64), need_dx=False)
     same(grad.cpu().numpy(), dw, "first-layer wgrad with fused BN-backward apply")
+
+
+ONE_BY_ONE = [(2, 16, 64, 64, 0, 32), (1, 31, 48, 128, 0, 64), (1, 62, 96, 256, 0, 128), (2, 8, 32, 32, 32, 64), (1, 24, 40, 512, 0, 256)]
+
+
+@pytest.mark.parametrize("shape", ONE_BY_ONE)
+def test_conv1x1_plain_fprop_dgrad_wgrad_bit_exact(env, shape):
+    """plain 1x1 convolutions (attention gates W_g / W_x, classifier heads) on the pipelined kernels: whole and ragged
+    tiles, BatchNorm partial sums, virtual concat, data gradient, weight gradient with the bias gradient fused in"""
+    L, E = env
+    n, h, w, c0, c1, cout = shape
+    cin = c0 + c1
+    rng = np.random.default_rng(abs(hash(shape)) % 2**32 + 11)
+    eng = E.UNetEngine(1, 2, 4, "bf16")
+    src, eff = exact_src(E, rng, n, h, w, c0, c1, True)
+    wt = pow2_weights(rng, (cout, cin, 1, 1), density=0.5)
+    wd = fdev(wt)
+    y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    part = torch.full((eng._stat_blocks(cout, n, h, w, src, taps=1), 2, cout), float("nan"), dtype=torch.float32, device="cuda")
+    eng._conv(src, eng._pack("w1", wd, L.PACK_1X1_FPROP, cout, cin), cout, 1, n, h, w, y, stats=part)
+    ref = np.einsum("bchw,oc->bohw", eff, wt[:, :, 0, 0].astype(np.float64))
+    same(host(y), to_bf16(ref), "1x1 fprop")
+    if np.abs(ref).sum(axis=(0, 2, 3)).max() * 8 < 2 ** 24:
+        same(part.double().sum(0).cpu().numpy()[0], ref.sum(axis=(0, 2, 3)), "1x1 sum(y)")
+    dy = ints(rng, (n, cout, h, w), -2, 2)
+    d0 = torch.full((n, h, w, c0), float("nan"), dtype=torch.bfloat16, device="cuda")
+    d1 = torch.full((n, h, w, c1), float("nan"), dtype=torch.bfloat16, device="cuda") if c1 else None
+    eng._conv(E.Src(dev(dy), cout), eng._pack("w1", wd, L.PACK_1X1_DGRAD, cout, cin), cin, 1, n, h, w, d0, y1=d1, split=c0 if c1 else 0)
+    dx = np.einsum("bohw,oc->bchw", dy.astype(np.float64), wt[:, :, 0, 0].astype(np.float64))
+    same(host(d0), to_bf16(dx[:, :c0]), "1x1 dgrad part 0")
+    if c1:
+        same(host(d1), to_bf16(dx[:, c0:]), "1x1 dgrad part 1")
+    db = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    dwp = eng._wgrad(src, dev(dy), cout, 1, n, h, w, dbias=db)
+    grad = torch.full((cout, cin, 1, 1), float("nan"), dtype=torch.float32, device="cuda")
+    eng._unpack(L.PACK_1X1_FPROP, dwp, grad, cout, cin, False)
+    torch.cuda.synchronize()
+    same(grad.cpu().numpy()[:, :, 0, 0], np.einsum("bohw,bchw->oc", dy.astype(np.float64), eff), "1x1 wgrad")
+    same(db.cpu().numpy(), dy.astype(np.float64).sum(axis=(0, 2, 3)), "1x1 bias gradient (ones-fragment MFMA)")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 64, 32, 0, 64), (1, 62, 96, 64, 64, 32)])
+def test_conv3x3_wgrad_with_fused_bias_gradient_bit_exact(env, shape):
+    """3x3 convolution with bias and no BatchNorm (conv_block.init_conv, common.py:9): db rides in the weight-gradient kernel"""
+    L, E = env
+    n, h, w, c0, c1, cout = shape
+    rng = np.random.default_rng(abs(hash(shape)) % 2**32 + 12)
+    eng = E.UNetEngine(1, 2, 4, "bf16")
+    src, eff = exact_src(E, rng, n, h, w, c0, c1, False)
+    dy = ints(rng, (n, cout, h, w), -2, 2)
+    db = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    dwp = eng._wgrad(src, dev(dy), cout, 9, n, h, w, dbias=db)
+    grad = torch.full((cout, c0 + c1, 3, 3), float("nan"), dtype=torch.float32, device="cuda")
+    eng._unpack(L.PACK_CONV_FPROP, dwp, grad, cout, c0 + c1, False)
+    torch.cuda.synchronize()
+    _, dw = O.conv3x3_bwd(eff, np.zeros((cout, c0 + c1, 3, 3)), dy.astype(np.float64), need_dx=False)
+    same(grad.cpu().numpy(), dw, "wgrad")
+    same(db.cpu().numpy(), dy.astype(np.float64).sum(axis=(0, 2, 3)), "bias gradient")
