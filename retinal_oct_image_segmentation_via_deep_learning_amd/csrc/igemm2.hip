@@ -109,9 +109,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // vmcnt queue (a global load issued at commit time would be YOUNGER than the prefetched stages and
   // waiting for it would drain the whole ring -- vmcnt retires in order)
   float* const sxf = reinterpret_cast<float*>(smem + 2 * BUFB) + (2 * WM * 2 * NT + 4);
-  unsigned char* const oscr = smem + 2 * BUFB + (2 * WM * 2 * NT + 4) * 4 + 2 * 1024 * 4;  // 4 waves x 32 px x 80 B
+  unsigned char* const oscr = smem + 2 * BUFB + (2 * WM * 2 * NT + 4) * 4 + 2 * 1024 * 4;  // 2 slots x 4 waves x 32 px x 80 B
   static_assert((2 * BUFB + (2 * WM * 2 * NT + 4) * 4) % 16 == 0, "scratch must stay 16-B aligned");
-  float* const sbias = reinterpret_cast<float*>(oscr + 4 * 32 * 80);   // [cout/4] deconv bias (D2S only)
+  float* const sbias = reinterpret_cast<float*>(oscr + 2 * 4 * 32 * 80);   // [cout/4] deconv bias (D2S only)
   // streamed-weight kernels: BatchNorm partial sums of ALL items of this workgroup, [2][cout]; one row
   // per workgroup reaches memory instead of one per tile (bn_finalize then reads <= 512 rows, not 16 k)
   float* const wgacc = sbias + 1024;
@@ -391,16 +391,16 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   // A fragment leaves in three moves: (1) bf16 pairs into the wave-private LDS scratch, pixel-major, so that
   // (2) consecutive lanes read back consecutive 16-B chunks (whole 64-B channel rows per pixel) and (3) store them.
-  auto frag_to_lds = [&](const unsigned (&pk)[8]) {
-    unsigned char* sc = oscr + wave * (32 * 80);
+  auto frag_to_lds = [&](const unsigned (&pk)[8], int slot = 0) {
+    unsigned char* sc = oscr + (slot * 4 + wave) * (32 * 80);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const u32x2 v = {pk[2 * g], pk[2 * g + 1]};
       *reinterpret_cast<u32x2*>(sc + r * 80 + (8 * g + 4 * hh) * 2) = v;   // pixel r, channels 8g+4hh..+3
     }
   };
-  auto frag_from_lds = [&](u32x4 (&tv)[2]) {
-    const unsigned char* sc = oscr + wave * (32 * 80);
+  auto frag_from_lds = [&](u32x4 (&tv)[2], int slot = 0) {
+    const unsigned char* sc = oscr + (slot * 4 + wave) * (32 * 80);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int chunk = lane + 64 * k;   // 128 chunks of 16 B: pixel = chunk / 4, part = chunk % 4
@@ -618,6 +618,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         }
       }
       if (!DEFER) set_item(img, tyi, txi, nbi);
+      // Not deferred (two channel fragments per wave): fragment f's bf16 pairs go to LDS scratch slot f & 1 while fragment
+      // f - 1 is read back from the other slot and stored, and the BatchNorm sums of f fill the LDS round trip -- back to
+      // back (write, wait, read, wait, store per fragment) the eight fragments took 6.3 k cycles per item (timeline, round 2).
+      u32x4 tvp[2];
+      int pm_ = -1, pq_ = 0, fidx = 0;
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
         // deconv bias from LDS (staged at kernel start): a global load here would put a vmcnt(0) --
@@ -649,7 +654,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
               packed[DEFER ? m : 0][DEFER ? q : 0][2 * g + 1] = pack_bf16x2(acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]);
             }
           }
-          if (!DEFER) store_frag(m, q);
+          if (!DEFER) {
+            frag_to_lds(packed[0][0], fidx & 1);
+            if (pm_ >= 0) { frag_from_lds(tvp, (fidx - 1) & 1); frag_store(pm_, pq_, tvp); }
+            pm_ = m; pq_ = q; ++fidx;
+          }
           if (STATS) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -659,6 +668,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           }
         }
       }
+      if (!DEFER) { frag_from_lds(tvp, (fidx - 1) & 1); frag_store(pm_, pq_, tvp); }
       if (DEFER) { set_item(img, tyi, txi, nbi); pend = true; }
       if (STATS && !WRES) {
         float* ws = wg_stats + parity * (WM * 2 * NT);
@@ -805,7 +815,7 @@ int oct_conv_v2_stat_rows(const OctConvDesc* d) {
 template <int WM, int WN, int MF, int NF, bool WRES>
 static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float) +
+  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 2 * 4 * 32 * 80 + 1024 * (int)sizeof(float) +
                   (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
   const bool ragged = (p.w % 32) != 0 || (p.h % TH) != 0;
   if (p.depth > 0) {   // volumetric: whole tiles only (plan_v2), streamed weights
@@ -822,7 +832,7 @@ static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
 template <int WM, int WN, int MF, int NF>
 static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  const int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 4 * 32 * 80 + 1024 * (int)sizeof(float) +
+  const int lds = 2 * TH * 32 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 2 * 4 * 32 * 80 + 1024 * (int)sizeof(float) +
                   (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
   const bool ragged = (p.w % 32) != 0 || (p.h % TH) != 0;
   if (p.in_mode == OCT_IN_PLAIN && p.out_mode == OCT_OUT_PLAIN && (p.stats || ragged)) {   // plain 1x1 convolution with BN sums / ragged tiles
