@@ -5,8 +5,27 @@
 // one atomic per wave and sum.
 #include "common.h"
 
+// wave -> workgroup -> ONE atomic per sum and workgroup.  Every workgroup of a metric kernel adds to the same few
+// words, and same-address atomics serialise at the memory side (~12 ns each): one per wave (8 k waves) cost 0.1-0.4 ms
+// on streams that take 10-70 us, so all kernels of this file are launched with <= 512 workgroups of 256 threads and
+// reduce through LDS first.
+template <int K, typename Acc>
+__device__ __forceinline__ void block_sum_atomic(Acc (&s)[K], Acc* out, int valid) {
+  __shared__ Acc red[4][K];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    Acc v = s[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < valid; k += blockDim.x) atomicAdd(&out[k], red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+}
+
 template <typename E, typename Acc>
-__global__ void confusion_kernel(const E* __restrict__ yt, const E* __restrict__ yp, size_t n, Acc* out) {
+__global__ void __launch_bounds__(256) confusion_kernel(const E* __restrict__ yt, const E* __restrict__ yp, size_t n, Acc* out) {
   constexpr int V = 16 / sizeof(E);
   Acc s[6] = {0, 0, 0, 0, 0, 0};
   const size_t nvec = n / V;
@@ -17,20 +36,25 @@ __global__ void confusion_kernel(const E* __restrict__ yt, const E* __restrict__
     s[0] += (Acc)(E)(t * p); s[1] += (Acc)t; s[2] += (Acc)p;
     s[3] += (Acc)(E)(nt * np_); s[4] += (Acc)(E)(nt * p); s[5] += (Acc)(E)(t * np_);
   };
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const VecT<E, V> a = reinterpret_cast<const VecT<E, V>*>(yt)[i];
-    const VecT<E, V> b = reinterpret_cast<const VecT<E, V>*>(yp)[i];
+  const VecT<E, V>* vt = reinterpret_cast<const VecT<E, V>*>(yt);
+  const VecT<E, V>* vp = reinterpret_cast<const VecT<E, V>*>(yp);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {   // four chunk pairs in flight per lane
+    VecT<E, V> a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = vt[i + u * stride]; b[u] = vp[i + u * stride]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < V; ++j) one(a[u].v[j], b[u].v[j]);
+  }
+  for (; i < nvec; i += stride) {
+    const VecT<E, V> a = vt[i], b = vp[i];
 #pragma unroll
     for (int j = 0; j < V; ++j) one(a.v[j], b.v[j]);
   }
-  for (size_t i = nvec * V + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) one(yt[i], yp[i]);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    Acc v = s[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&out[k], v);
-  }
+  for (size_t k = nvec * V + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) one(yt[k], yp[k]);
+  block_sum_atomic<6, Acc>(s, out, 6);
 }
 
 // uint8 / bool masks -- the evaluation case (32 x 512 x 1024 masks = 33.5 MB per pass).  A 16-byte chunk pair whose
@@ -87,19 +111,7 @@ __global__ void __launch_bounds__(256) confusion_u8_kernel(const uint8_t* __rest
   // binary chunks: tn = n - t - p + tp, fp = p - tp, fn = t - tp
   s[0] += btp; s[1] += bt; s[2] += bp;
   s[3] += (unsigned long long)bn - bt - bp + btp; s[4] += bp - btp; s[5] += bt - btp;
-  // wave -> workgroup -> ONE atomic per sum and workgroup: every workgroup adds to the same six words, and same-address
-  // atomics serialise at the memory side (~12 ns each): 12 k of them (one per wave) cost 0.12 ms on a 5 us stream
-  __shared__ unsigned long long red[4][6];
-  const int wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    unsigned long long v = s[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) red[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) atomicAdd(&out[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  block_sum_atomic<6, unsigned long long>(s, out, 6);
 }
 
 __global__ void zero_counts_kernel(unsigned long long* oi, double* of) {
@@ -117,7 +129,7 @@ extern "C" int oct_confusion_counts(const void* y_true, const void* y_pred, int 
   hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, s, oi, out_f);
   if (n > 0) {
     size_t b = (n + 256 * 64 - 1) / (256 * 64);
-    if (b > 2048) b = 2048;
+    if (b > 512) b = 512;   // two workgroups per CU, 3 k same-address atomics in all
     if (b < 1) b = 1;
     const dim3 g((int)b), t(256);
     typedef unsigned long long u64;
@@ -146,13 +158,16 @@ extern "C" int oct_confusion_counts(const void* y_true, const void* y_pred, int 
 // masks (t == c), (p == c) -- i.e. what the reference's formulas (Region_based_metrics.py:3-61,
 // ConfusionMatrix_based_metrics.py:4-63) see when a caller evaluates class c one-vs-rest, for all classes at
 // once instead of one upload + 3-4 passes per class and metric.  Per-lane 32-bit counters [3][16] in
-// registers (a lane sees < 2^32 pixels), flushed with a wave reduction + one 64-bit atomic per wave and sum.
+// registers (a lane sees < 2^32 pixels), flushed with a wave + workgroup reduction and one 64-bit atomic per
+// workgroup and sum (block_sum_atomic).
 // ---------------------------------------------------------------------------------------------
 #define OCT_METRIC_MAX_CLASSES 16
-template <typename E>
+// C = the class count rounded up to 4 / 8 / 16: the kernel is issue-bound (~5 vector ops per pixel and class), so an
+// 8-class map costs half of a 16-class one.
+template <typename E, int C>
 __global__ void __launch_bounds__(256) class_confusion_kernel(const E* __restrict__ yt, const E* __restrict__ yp, size_t n,
-                                                              int classes, unsigned long long* raw /* [3][16] */) {
-  constexpr int V = 16 / sizeof(E), C = OCT_METRIC_MAX_CLASSES;
+                                                              unsigned long long* raw /* [3][16] */) {
+  constexpr int V = 16 / sizeof(E), CM = OCT_METRIC_MAX_CLASSES;
   unsigned tp[C], ct[C], cp[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) { tp[c] = 0; ct[c] = 0; cp[c] = 0; }
@@ -164,20 +179,34 @@ __global__ void __launch_bounds__(256) class_confusion_kernel(const E* __restric
     }
   };
   const size_t nvec = n / V, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const VecT<E, V> a = reinterpret_cast<const VecT<E, V>*>(yt)[i];
-    const VecT<E, V> b = reinterpret_cast<const VecT<E, V>*>(yp)[i];
+  const VecT<E, V>* vt = reinterpret_cast<const VecT<E, V>*>(yt);
+  const VecT<E, V>* vp = reinterpret_cast<const VecT<E, V>*>(yp);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < nvec; i += 2 * stride) {   // two chunk pairs in flight per lane
+    const VecT<E, V> a0 = vt[i], b0 = vp[i], a1 = vt[i + stride], b1 = vp[i + stride];
+#pragma unroll
+    for (int j = 0; j < V; ++j) one(a0.v[j], b0.v[j]);
+#pragma unroll
+    for (int j = 0; j < V; ++j) one(a1.v[j], b1.v[j]);
+  }
+  for (; i < nvec; i += stride) {
+    const VecT<E, V> a = vt[i], b = vp[i];
 #pragma unroll
     for (int j = 0; j < V; ++j) one(a.v[j], b.v[j]);
   }
-  for (size_t i = nvec * V + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) one(yt[i], yp[i]);
+  for (size_t k = nvec * V + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) one(yt[k], yp[k]);
+  unsigned long long s[C];   // raw layout: [tp | t | p][16]; classes beyond C stay zero
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    unsigned long long a = tp[c], b = ct[c], d = cp[c];
+  for (int c = 0; c < C; ++c) s[c] = tp[c];
+  block_sum_atomic<C, unsigned long long>(s, raw, C);
+  __syncthreads();
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); d += __shfl_xor(d, o); }
-    if ((threadIdx.x & 63) == 0 && c < classes) { atomicAdd(&raw[c], a); atomicAdd(&raw[C + c], b); atomicAdd(&raw[2 * C + c], d); }
-  }
+  for (int c = 0; c < C; ++c) s[c] = ct[c];
+  block_sum_atomic<C, unsigned long long>(s, raw + CM, C);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < C; ++c) s[c] = cp[c];
+  block_sum_atomic<C, unsigned long long>(s, raw + 2 * CM, C);
 }
 __global__ void class_confusion_zero_kernel(unsigned long long* raw) { if (threadIdx.x < 3 * OCT_METRIC_MAX_CLASSES) raw[threadIdx.x] = 0ull; }
 // out[c] = { tp, t, p, tn, fp, fn } of the one-vs-rest masks of class c
@@ -202,9 +231,14 @@ extern "C" int oct_class_confusion_counts(const void* y_true, const void* y_pred
   hipLaunchKernelGGL(class_confusion_zero_kernel, dim3(1), dim3(64), 0, s, raw);
   if (n > 0) {
     size_t b = (n + 256 * 64 - 1) / (256 * 64);
-    if (b > 2048) b = 2048;
+    if (b > 1024) b = 1024;   // issue-bound (~80 vector ops per pixel): four workgroups per CU
     const dim3 g((int)b), t(256);
-#define CC(E) hipLaunchKernelGGL((class_confusion_kernel<E>), g, t, 0, s, (const E*)y_true, (const E*)y_pred, n, classes, raw)
+#define CC(E)                                                                                                              \
+  do {                                                                                                                       \
+    if (classes <= 4) hipLaunchKernelGGL((class_confusion_kernel<E, 4>), g, t, 0, s, (const E*)y_true, (const E*)y_pred, n, raw);       \
+    else if (classes <= 8) hipLaunchKernelGGL((class_confusion_kernel<E, 8>), g, t, 0, s, (const E*)y_true, (const E*)y_pred, n, raw);  \
+    else hipLaunchKernelGGL((class_confusion_kernel<E, 16>), g, t, 0, s, (const E*)y_true, (const E*)y_pred, n, raw);        \
+  } while (0)
     switch (elem) {
       case 0: CC(uint8_t); break; case 1: CC(int32_t); break; case 2: CC(int64_t); break;
       case 5: CC(int8_t); break; case 6: CC(int16_t); break; default: CC(uint16_t); break;
@@ -220,29 +254,39 @@ extern "C" int oct_class_confusion_counts(const void* y_true, const void* y_pred
 // Metrics/PixelError_based_metrics.py:3-37  --  sum of (double(t) - double(p))^2 in one pass
 // ---------------------------------------------------------------------------------------------
 template <typename E>
-__global__ void sqdiff_kernel(const E* __restrict__ yt, const E* __restrict__ yp, size_t n, double* out) {
+__global__ void __launch_bounds__(256) sqdiff_kernel(const E* __restrict__ yt, const E* __restrict__ yp, size_t n, double* out) {
   constexpr int V = 16 / sizeof(E);
-  double s = 0.0;
+  double s[1] = {0.0};
   const size_t nvec = n / V, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const VecT<E, V> a = reinterpret_cast<const VecT<E, V>*>(yt)[i];
-    const VecT<E, V> b = reinterpret_cast<const VecT<E, V>*>(yp)[i];
+  const VecT<E, V>* vt = reinterpret_cast<const VecT<E, V>*>(yt);
+  const VecT<E, V>* vp = reinterpret_cast<const VecT<E, V>*>(yp);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {   // four chunk pairs in flight per lane
+    VecT<E, V> a[4], b[4];
 #pragma unroll
-    for (int j = 0; j < V; ++j) { const double d = (double)a.v[j] - (double)b.v[j]; s = fma(d, d, s); }
+    for (int u = 0; u < 4; ++u) { a[u] = vt[i + u * stride]; b[u] = vp[i + u * stride]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < V; ++j) { const double d = (double)a[u].v[j] - (double)b[u].v[j]; s[0] = fma(d, d, s[0]); }
   }
-  for (size_t i = nvec * V + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double d = (double)yt[i] - (double)yp[i];
-    s = fma(d, d, s);
+  for (; i < nvec; i += stride) {
+    const VecT<E, V> a = vt[i], b = vp[i];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { const double d = (double)a.v[j] - (double)b.v[j]; s[0] = fma(d, d, s[0]); }
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  for (size_t k = nvec * V + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const double d = (double)yt[k] - (double)yp[k];
+    s[0] = fma(d, d, s[0]);
+  }
+  block_sum_atomic<1, double>(s, out, 1);
 }
 
 // Metrics/Biomarker_based_metrics.py:3-21  --  sum over columns j of |sum_i t[i][j] - sum_i p[i][j]|
 // with numpy's dtype semantics: column sums in uint64 (unsigned inputs: the difference WRAPS, exactly
 // like the reference), int64 (signed and bool inputs) or the float type.
 template <typename E, typename Acc, bool WRAP>
-__global__ void column_absdiff_kernel(const E* __restrict__ yt, const E* __restrict__ yp, size_t rows, size_t cols,
+__global__ void __launch_bounds__(256) column_absdiff_kernel(const E* __restrict__ yt, const E* __restrict__ yp, size_t rows, size_t cols,
                                       double* out) {
   double s = 0.0;
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < cols; j += (size_t)gridDim.x * blockDim.x) {
@@ -255,8 +299,51 @@ __global__ void column_absdiff_kernel(const E* __restrict__ yt, const E* __restr
       s += (double)(d < 0 ? -d : d);
     }
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  double r[1] = {s};
+  block_sum_atomic<1, double>(r, out, 1);
+}
+
+// the same with 16-byte loads: a lane owns V = 16/sizeof(E) adjacent columns (cols % V == 0, 16-byte aligned bases)
+// and keeps four rows in flight; the scalar kernel above reads one element per lane and row (64 B per wave load).
+template <typename E, typename Acc, bool WRAP>
+__global__ void __launch_bounds__(256) column_absdiff_vec_kernel(const E* __restrict__ yt, const E* __restrict__ yp, size_t rows,
+                                                                 size_t cols, double* out) {
+  constexpr int V = 16 / sizeof(E);
+  const size_t cv = cols / V;
+  const VecT<E, V>* vt = reinterpret_cast<const VecT<E, V>*>(yt);
+  const VecT<E, V>* vp = reinterpret_cast<const VecT<E, V>*>(yp);
+  double s = 0.0;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < cv; j += (size_t)gridDim.x * blockDim.x) {
+    Acc st[V], sp[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { st[k] = 0; sp[k] = 0; }
+    size_t i = 0;
+    for (; i + 4 <= rows; i += 4) {
+      VecT<E, V> a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a[u] = vt[(i + u) * cv + j]; b[u] = vp[(i + u) * cv + j]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < V; ++k) { st[k] += (Acc)a[u].v[k]; sp[k] += (Acc)b[u].v[k]; }
+    }
+    for (; i < rows; ++i) {
+      const VecT<E, V> a = vt[i * cv + j], b = vp[i * cv + j];
+#pragma unroll
+      for (int k = 0; k < V; ++k) { st[k] += (Acc)a.v[k]; sp[k] += (Acc)b.v[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {   // column order within the lane, like the scalar kernel's per-column terms
+      if (WRAP) {
+        s += (double)(unsigned long long)((unsigned long long)st[k] - (unsigned long long)sp[k]);
+      } else {
+        const Acc d = st[k] - sp[k];
+        s += (double)(d < 0 ? -d : d);
+      }
+    }
+  }
+  double r[1] = {s};
+  block_sum_atomic<1, double>(r, out, 1);
 }
 
 __global__ void zero_f64_kernel(double* p) { if (threadIdx.x == 0) *p = 0.0; }
@@ -270,7 +357,7 @@ extern "C" int oct_sqdiff_sum(const void* y_true, const void* y_pred, int elem, 
   hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(64), 0, s, out);
   if (n > 0) {
     size_t b = (n + 256 * 64 - 1) / (256 * 64);
-    if (b > 2048) b = 2048;
+    if (b > 512) b = 512;
     const dim3 g((int)b), t(256);
 #define SQ(E) hipLaunchKernelGGL((sqdiff_kernel<E>), g, t, 0, s, (const E*)y_true, (const E*)y_pred, n, out)
     switch (elem) {
@@ -290,12 +377,19 @@ extern "C" int oct_column_absdiff_sum(const void* y_true, const void* y_pred, in
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(64), 0, s, out);
   if (rows * cols > 0) {
-    size_t b = (cols + 255) / 256;
-    if (b > 2048) b = 2048;
-    const dim3 g((int)b), t(256);
     typedef unsigned long long u64;
     typedef long long i64;
-#define CA(E, A, W) hipLaunchKernelGGL((column_absdiff_kernel<E, A, W>), g, t, 0, s, (const E*)y_true, (const E*)y_pred, rows, cols, out)
+    static const int esz[8] = {1, 4, 8, 4, 8, 1, 2, 2};
+    const size_t v = 16 / esz[elem];
+    const bool vec = cols % v == 0 && (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
+    size_t b = ((vec ? cols / v : cols) + 255) / 256;
+    if (b > 512) b = 512;
+    const dim3 g((int)b), t(256);
+#define CA(E, A, W)                                                                                                              \
+  do {                                                                                                                           \
+    if (vec) hipLaunchKernelGGL((column_absdiff_vec_kernel<E, A, W>), g, t, 0, s, (const E*)y_true, (const E*)y_pred, rows, cols, out); \
+    else hipLaunchKernelGGL((column_absdiff_kernel<E, A, W>), g, t, 0, s, (const E*)y_true, (const E*)y_pred, rows, cols, out);  \
+  } while (0)
     switch (elem) {
       case 0: if (unsigned_wrap) CA(uint8_t, u64, true); else CA(uint8_t, i64, false); break;
       case 1: CA(int32_t, i64, false); break;

@@ -75,6 +75,21 @@ def test_uint8_wraparound_matches_numpy(mods):
     assert float(mods["region.dice_coefficient"](e, e)) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.int16, np.uint16, np.int32, np.int64, np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(7, 64), (5, 3, 48), (9, 33), (1, 16), (4096, 16)])
+def test_column_difference_and_squared_error_paths(mods, dtype, shape):
+    """16-byte-vector (cols % (16/size) == 0) and scalar column kernels, row counts around the 4-row unroll, every
+    element type: the Biomarker / PixelError answers equal the numpy restatement (uint inputs wrap like numpy)."""
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(11)
+    hi = 2 if np.dtype(dtype).kind != "f" else 1
+    a = (rng.integers(0, hi + 1, shape) if np.dtype(dtype).kind != "f" else rng.random(shape)).astype(dtype)
+    b = (rng.integers(0, hi + 1, shape) if np.dtype(dtype).kind != "f" else rng.random(shape)).astype(dtype)
+    for fname in ("bio.thickness_difference", "pixel.mean_squared_error", "pixel.root_mean_squared_error"):
+        np.testing.assert_allclose(float(mods[fname](a, b)), float(O.METRIC_FUNCS[fname](a, b)),
+                                   rtol=1e-12 if dtype != np.float32 else 1e-5, err_msg=fname)
+
+
 def test_one_pass_evaluate_and_device_tensor_cache(golden_dir, mods):
     """dice + iou + precision + recall + accuracy + ... on one pair: ONE confusion pass, not one per metric"""
     from retinal_oct_image_segmentation_via_deep_learning_amd import Metrics
@@ -108,14 +123,15 @@ def test_one_pass_evaluate_and_device_tensor_cache(golden_dir, mods):
     assert _counts.launch_count[0] == n0 + 3
 
 
-@pytest.mark.parametrize("dtype", [np.uint8, np.int64, np.int32, np.int16])
-def test_per_class_counts_one_pass_match_one_vs_rest_reference(dtype):
-    """class maps in, [C][6] counts out: equal to the reference formulas on (y == c) masks for every class"""
+@pytest.mark.parametrize("dtype,C", [(np.uint8, 9), (np.int64, 9), (np.int32, 9), (np.int16, 9), (np.uint8, 3), (np.uint8, 8),
+                                     (np.int64, 4), (np.uint8, 16), (np.int64, 16)])
+def test_per_class_counts_one_pass_match_one_vs_rest_reference(dtype, C):
+    """class maps in, [C][6] counts out: equal to the reference formulas on (y == c) masks for every class (class
+    counts on either side of the kernel's 4 / 8 / 16 instances; labels beyond C are present)"""
     from oracle import ref_cpu
     from retinal_oct_image_segmentation_via_deep_learning_amd import Metrics
     from retinal_oct_image_segmentation_via_deep_learning_amd.Metrics import _counts
     rng = np.random.default_rng(5)
-    C = 9
     yt = rng.integers(0, C, (3, 37, 53)).astype(dtype)
     yp = np.where(rng.random(yt.shape) < 0.7, yt, rng.integers(0, C + 2, yt.shape)).astype(dtype)   # some labels out of range
     n0 = _counts.launch_count[0]

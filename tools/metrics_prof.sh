@@ -9,10 +9,10 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]
 print("\nrocprofv3 --kernel-trace --stats (kernel durations only):")
 n = 32 * 512 * 1024
-byt = {"confusion_u8": 2 * n, "confusion_kernel": 16 * n, "class_confusion_kernelIh": 2 * n, "class_confusion_kernelIl": 16 * n,
-       "sqdiff": 2 * n, "column_absdiff": 2 * n}
+byt = [("confusion_u8", 2 * n), ("class_confusion_kernel<unsigned char>", 2 * n), ("class_confusion_kernel<long>", 16 * n),
+       (" confusion_kernel<long", 16 * n), ("sqdiff", 2 * n), ("column_absdiff", 2 * n)]
 for r in csv.DictReader(open(f)):
-    for k, b in byt.items():
+    for k, b in byt:
         if k in r["Name"]:
             us = float(r["AverageNs"]) / 1e3
             print(f"{r['Name'][:70]:70s} x{r['Calls']:>4s}  avg {us:8.1f} us  {b / us / 1e3:7.0f} GB/s  ({b / us / 1e3 / 6300:4.2f} of 6.3 TB/s)")
