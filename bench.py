@@ -82,6 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive side measurement (N = 1)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercise the multi-rank plumbing on CPU tensors")
     ap.add_argument("--bucket-mb", type=float, default=3.0, help="gradient bucket threshold (MB)")
@@ -359,6 +360,44 @@ def side_config(args) -> int:
     return 0
 
 
+def pcie_inclusive(args, trainer, x, t):
+    """The same step fed from PINNED HOST buffers: batch k+1 crosses PCIe on a copy stream (fp32 image + int64 target,
+    two device slots) while batch k trains.  Reported next to `value`, never as `value` (inputs resident is the
+    contract); N = 1 only."""
+    import torch
+    hx, ht = x.cpu().pin_memory(), t.cpu().pin_memory()
+    dx, dt = [torch.empty_like(x) for _ in range(2)], [torch.empty_like(t) for _ in range(2)]
+    copy = torch.cuda.Stream()
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+    for e in free:
+        e.record()
+
+    def stage(i):
+        with torch.cuda.stream(copy):
+            copy.wait_event(free[i])
+            dx[i].copy_(hx, non_blocking=True)
+            dt[i].copy_(ht, non_blocking=True)
+            ready[i].record(copy)
+
+    steps = max(4, min(args.steps, 20))
+    stage(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        i = k & 1
+        if k + 1 < steps:
+            stage(i ^ 1)
+        torch.cuda.current_stream().wait_event(ready[i])
+        trainer.step(dx[i], dt[i])
+        free[i].record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": round(args.batch * steps / el, 2), "unit": "B-scans/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+            "host_bytes_per_step": hx.numel() * hx.element_size() + ht.numel() * ht.element_size(),
+            "how": "pinned host batch -> device on a copy stream, double buffered, overlapped with the previous step"}
+
+
 def worker(args) -> int:
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
@@ -440,6 +479,10 @@ def worker(args) -> int:
         "whole_step_frac": round(value / world * flops_bscan / 1e12 / PEAK_BF16_TFLOPS, 4),
     }
 
+    pcie = None
+    if world == 1 and not args.no_h2d:
+        pcie = pcie_inclusive(args, trainer, x, t)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -460,7 +503,7 @@ def worker(args) -> int:
                        "grad_buckets_bytes": [4 * (hi - lo) for _, lo, hi in trainer.reducer.buckets],
                        "hip_graph": graph_used, "hip_graph_error": trainer.graph_error},
             "loss": float(loss[0].item()),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -245,6 +245,10 @@ int oct_bn_bwd_finalize(const float* partials, int nblocks, int c, double count,
  * mask [y*scale+shift > 0] is applied here (pairs with oct_dact_bn_reduce(g = NULL), reduce-only). */
 int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const float* scale,
                      const float* shift, size_t npix, int c, void* stream);
+/* The same, written to `dst` (g is left intact: a gradient that autograd still hands to another consumer -- the
+ * residual branch of SD_Layer_Net's conv_block, common.py:22-25 -- needs no copy first). dst == g is allowed.   */
+int oct_bn_bwd_apply_to(int dtype, void* dst, const void* g, const void* y, const float* coef, const float* scale,
+                        const float* shift, size_t npix, int c, void* stream);
 /* per-channel sum over pixels of an NHWC tensor (bias gradient of ConvTranspose2d) */
 int oct_channel_sum(int dtype, const void* x, float* out, size_t npix, int c, int accumulate,
                     void* stream);

@@ -111,6 +111,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_int, c_void_p]),
     "oct_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                  c_void_p]),
+    "oct_bn_bwd_apply_to": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
+                                    c_void_p]),
     "oct_channel_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "oct_head_blocks": (c_int, [C.POINTER(HeadDesc)]),
     "oct_head_forward": (c_int, [C.POINTER(HeadDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

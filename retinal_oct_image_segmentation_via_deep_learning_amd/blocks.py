@@ -174,10 +174,12 @@ class conv_block(HipModule):
         self.activation = act()
 
     def nhwc(self, a, a1=None):
+        """a / a1: NHWC tensors or ops.LazyAct (BN + ReLU of the producer applied on load)."""
         _check_dropout(self)
         dt = self.compute_dtype
         i = ops.conv_bn_act(dt, a, self.init_conv, x1=a1)
-        t = ops.conv_bn_act(dt, i, self.conv[0], self.conv[1], L.ACT_RELU)
+        # relu(bn(conv0(i))) has one consumer, a convolution: it is never written (deferred activation)
+        t = ops.conv_bn_act(dt, i, self.conv[0], self.conv[1], L.ACT_RELU, lazy=True)
         return ops.conv_bn_act(dt, t, self.conv[4], self.conv[5], L.ACT_RELU, res=i)
 
     def forward(self, x):
@@ -199,10 +201,12 @@ class up_conv(HipModule):
             nn.Conv2d(ch_in, ch_out, kernel_size=3, stride=1, padding=1, bias=True), nn.BatchNorm2d(ch_out),
             nn.Dropout2d(drop_rate, inplace=True), act())
 
-    def nhwc(self, a):
+    def nhwc(self, a, lazy=False):
+        """lazy=True: the caller feeds the result to convolutions only (U_Net / AttU_Net: the gate's W_g and the
+        concatenating conv_block) and gets an ops.LazyAct."""
         _check_dropout(self)
         dt = self.compute_dtype
-        return ops.conv_bn_act(dt, ops.BilinearUp.apply(dt, self._factor, a), self.up[1], self.up[2], L.ACT_RELU)
+        return ops.conv_bn_act(dt, ops.BilinearUp.apply(dt, self._factor, a), self.up[1], self.up[2], L.ACT_RELU, lazy=lazy)
 
     def forward(self, x):
         return self._out(self.nhwc(self._in(x)))
@@ -266,7 +270,7 @@ class _SDUNetBase(HipModule):
         d = feats[-1]
         for i in range(self._levels, 1, -1):
             skip = feats[i - 2]
-            d = getattr(self, f"Up{i}").nhwc(d)
+            d = getattr(self, f"Up{i}").nhwc(d, lazy=True)
             att = getattr(self, f"Att{i}", None)
             if att is not None:
                 skip = att.nhwc(d, skip)

@@ -513,7 +513,7 @@ extern "C" int oct_bn_bwd_finalize(const float* partials, int nblocks, int c, do
 // masked != 0: `g` holds dA (gradient w.r.t. the activation); the ReLU mask [y*scale+shift > 0] is
 // re-derived here, so the reduction pass before it never has to write a masked copy.
 template <typename T, int V>
-__global__ void bn_bwd_apply_kernel(T* g, const T* __restrict__ y, const float* __restrict__ coef,
+__global__ void bn_bwd_apply_kernel(T* dst, const T* g, const T* __restrict__ y, const float* __restrict__ coef,
                                     const float* __restrict__ scale, const float* __restrict__ shift, size_t npix, int c) {
   const int G = c / V;
   const size_t total = npix * G;
@@ -531,12 +531,12 @@ __global__ void bn_bwd_apply_kernel(T* g, const T* __restrict__ y, const float* 
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) gv[j] = fmaf(k0[j], gv[j], fmaf(k1[j], yv[j], k2[j]));
-    store_vec<T, V>(g + pix * c + gi * V, gv);
+    store_vec<T, V>(dst + pix * c + gi * V, gv);
   }
 }
 // flat variant (see dact_bn_reduce_flat_kernel): coefficients once per thread, no index arithmetic
 template <typename T, int U>
-__global__ void __launch_bounds__(EW_THREADS) bn_bwd_apply_flat_kernel(T* g, const T* __restrict__ y,
+__global__ void __launch_bounds__(EW_THREADS) bn_bwd_apply_flat_kernel(T* dst, const T* g, const T* __restrict__ y,
                                                                       const float* __restrict__ coef,
                                                                       const float* __restrict__ scale,
                                                                       const float* __restrict__ shift, size_t total, int c) {
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(EW_THREADS) bn_bwd_apply_flat_kernel(T* g, con
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) gv[j] = fmaf(k0[j], gv[j], fmaf(k1[j], yv[j], k2[j]));
-    store_vec_nt<T, V>(g + at * V, gv);
+    store_vec_nt<T, V>(dst + at * V, gv);
   };
   for (; i + (U - 1) * stride < total; i += U * stride) {
     float gv[U][V], yv[U][V];
@@ -570,9 +570,9 @@ __global__ void __launch_bounds__(EW_THREADS) bn_bwd_apply_flat_kernel(T* g, con
     one(gv, yv, i);
   }
 }
-extern "C" int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const float* scale,
-                                const float* shift, size_t npix, int c, void* stream) {
-  OCT_CHECK(g && y && coef && npix > 0 && c > 0, "oct_bn_bwd_apply: bad args");
+extern "C" int oct_bn_bwd_apply_to(int dtype, void* dst, const void* g, const void* y, const float* coef, const float* scale,
+                                   const float* shift, size_t npix, int c, void* stream) {
+  OCT_CHECK(dst && g && y && coef && npix > 0 && c > 0, "oct_bn_bwd_apply: bad args");
   OCT_CHECK((scale == nullptr) == (shift == nullptr), "oct_bn_bwd_apply: scale/shift mismatch");
   const int v = vec_width(c);
   const int blocks = ew_blocks(npix, c / v);
@@ -580,22 +580,26 @@ extern "C" int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* 
   if (v == 8 && lane_mapping_ok(c, 8)) {
     const size_t total = npix * (size_t)(c / 8);
     if (dtype == OCT_DT_BF16)
-      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<bf16_t, 1>), dim3(blocks), dim3(EW_THREADS), 0, s, (bf16_t*)g,
-                         (const bf16_t*)y, coef, scale, shift, total, c);
+      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<bf16_t, 1>), dim3(blocks), dim3(EW_THREADS), 0, s, (bf16_t*)dst,
+                         (const bf16_t*)g, (const bf16_t*)y, coef, scale, shift, total, c);
     else if (dtype == OCT_DT_F32)
-      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<float, 1>), dim3(blocks), dim3(EW_THREADS), 0, s, (float*)g,
-                         (const float*)y, coef, scale, shift, total, c);
+      hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<float, 1>), dim3(blocks), dim3(EW_THREADS), 0, s, (float*)dst,
+                         (const float*)g, (const float*)y, coef, scale, shift, total, c);
     else
       OCT_CHECK(false, "oct_bn_bwd_apply: bad dtype");
     return oct_check_launch("bn_bwd_apply_flat");
   }
-#define LAUNCH(T, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(blocks), dim3(EW_THREADS), 0, s, (T*)g, \
-                                        (const T*)y, coef, scale, shift, npix, c)
+#define LAUNCH(T, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(blocks), dim3(EW_THREADS), 0, s, (T*)dst, \
+                                        (const T*)g, (const T*)y, coef, scale, shift, npix, c)
   if (dtype == OCT_DT_BF16) { if (v == 8) LAUNCH(bf16_t, 8); else LAUNCH(bf16_t, 1); }
   else if (dtype == OCT_DT_F32) { if (v == 8) LAUNCH(float, 8); else LAUNCH(float, 1); }
   else OCT_CHECK(false, "oct_bn_bwd_apply: bad dtype");
 #undef LAUNCH
   return oct_check_launch("bn_bwd_apply");
+}
+extern "C" int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const float* scale,
+                                const float* shift, size_t npix, int c, void* stream) {
+  return oct_bn_bwd_apply_to(dtype, g, g, y, coef, scale, shift, npix, c, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

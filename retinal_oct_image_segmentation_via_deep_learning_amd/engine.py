@@ -160,6 +160,7 @@ class UNetEngine:
         self._arena, self._arena_on, self._arena_off, self._arena_short = None, False, 0, False
         self._unpack_jobs = []
         self._nbt = []
+        self._consts = {}  # (value, n, device) -> constant fp32 vector (never written)
         # deterministic = True: weight gradients through the two-stage reduction (OctWgradDesc.partials: per-workgroup slabs
         # summed in order) instead of fp32 atomics -- bit-identical gradients from run to run (OCT_DETERMINISTIC=1 sets it)
         self.deterministic = os.environ.get("OCT_DETERMINISTIC", "0") == "1"
@@ -188,6 +189,13 @@ class UNetEngine:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
             self.prof.append((kind, ev, end))
+
+    def _const(self, value: float, n: int, dev):
+        key = (float(value), int(n), str(dev))
+        t = self._consts.get(key)
+        if t is None:
+            t = self._consts[key] = torch.full((n,), float(value), dtype=torch.float32, device=dev)
+        return t
 
     def _act(self, n, h, w, c, dev):
         return torch.empty((n, h, w, c), dtype=self.tdt, device=dev)

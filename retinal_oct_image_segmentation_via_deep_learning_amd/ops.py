@@ -16,7 +16,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .engine import BN_EPS, BN_MOMENTUM, Src, UNetEngine, _stream
+from .engine import BN_EPS, BN_MOMENTUM, BNState, Src, UNetEngine, _stream
 
 _engines: dict = {}
 
@@ -101,16 +101,35 @@ class ToNCHW(torch.autograd.Function):
         return ToNHWC.apply(dout, ctx.dtype), None
 
 
+class LazyAct:
+    """relu(scale * y + shift) that is never written: `y` is the raw convolution output and the consumers -- convolutions
+    only -- apply BatchNorm + ReLU while they stage their input (the deferred-activation schedule of `engine.UNetEngine`,
+    here between autograd ops).  Values are bit-identical to the materialised tensor (same fma, same bf16 rounding)."""
+    __slots__ = ("y", "scale", "shift")
+
+    def __init__(self, y, scale, shift):
+        self.y, self.scale, self.shift = y, scale, shift
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+
 class ConvAffineAct(torch.autograd.Function):
     """out = act(affine(conv(cat(x0, x1), w)) (+ res)) with affine = train/eval BatchNorm (bn given) or
     `+ bias` (bn None).  3x3 pad 1, 1x1 or 7x3 pad (3,1) (ReLayNet_2017.py:155-160), chosen by the weight's shape.
     act = ACT_PRELU takes `alpha` (nn.PReLU's single slope) and returns its gradient.
 
     bn: the nn.BatchNorm2d container (running buffers are updated in train mode, momentum 0.1).
-    A conv bias in front of a train-mode BN only moves the running mean; its gradient is zero."""
+    A conv bias in front of a train-mode BN only moves the running mean; its gradient is zero.
+
+    xf0 / xf1 = (scale, shift): that input is a LazyAct's raw tensor, BN + ReLU are applied on load (forward, weight
+    gradient) and the data gradient returned for it is the gradient w.r.t. the ACTIVATED tensor.
+    lazy: train-mode BN + ReLU without residual -- return (y, scale, shift) instead of the activated tensor; backward
+    then takes dA, re-derives the ReLU mask from y (no stored activation, no separate mask pass)."""
 
     @staticmethod
-    def forward(ctx, dtype, bn, act, x0, x1, w, cbias, gamma, beta, res, alpha=None):
+    def forward(ctx, dtype, bn, act, x0, x1, w, cbias, gamma, beta, res, alpha=None, xf0=None, xf1=None, lazy=False):
         e = kernels(dtype)
         lib = L.lib()
         x0 = x0.contiguous()
@@ -129,7 +148,9 @@ class ConvAffineAct(torch.autograd.Function):
         if act == L.ACT_PRELU and (alpha is None or res is not None):
             raise RuntimeError("PReLU needs its slope parameter (and takes no residual)")
         dev = x0.device
-        src = Src(x0, c0, None, x1, c1, None)
+        src = Src(x0, c0, BNState(*xf0) if xf0 else None, x1, c1, BNState(*xf1) if xf1 else None)
+        if lazy and not (bn is not None and bn.training and act == L.ACT_RELU and res is None):
+            raise RuntimeError("a lazy output needs a train-mode BatchNorm + ReLU without residual")
         wp = packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
         y = e._act(n, h, wd, cout, dev)
         scale = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -159,6 +180,12 @@ class ConvAffineAct(torch.autograd.Function):
                     shift.copy_(cbias.detach())
                 else:
                     shift.zero_()
+        ctx.cfg = (dtype, bn, act, taps, train_bn, res is not None, cbias is not None, kk, lazy)
+        ctx.xf = (xf0, xf1)
+        if lazy:
+            ctx.save_for_backward(x0, x1, w, y, None, mean, invstd, scale, gamma, shift, alpha)
+            ctx.mark_non_differentiable(scale, shift)
+            return y, scale, shift
         out = e._act(n, h, wd, cout, dev)
         if res is not None:
             res = res.contiguous()
@@ -168,13 +195,13 @@ class ConvAffineAct(torch.autograd.Function):
         else:
             L.check(lib.oct_affine_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), act,
                                            out.data_ptr(), n * h * wd, cout, _stream()), "oct_affine_act_fwd")
-        ctx.cfg = (dtype, bn, act, taps, train_bn, res is not None, cbias is not None, kk)
         ctx.save_for_backward(x0, x1, w, y, out, mean, invstd, scale, gamma, shift, alpha)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        dtype, bn, act, taps, train_bn, has_res, has_bias, kk = ctx.cfg
+    def backward(ctx, dout, *_unused):
+        dtype, bn, act, taps, train_bn, has_res, has_bias, kk, lazy = ctx.cfg
+        xf0, xf1 = ctx.xf
         x0, x1, w, y, out, mean, invstd, scale, gamma, shift, alpha = ctx.saved_tensors
         kd = dict(kh=kk[0], kw=kk[1]) if kk else {}
         dalpha = None
@@ -189,7 +216,9 @@ class ConvAffineAct(torch.autograd.Function):
         dout = dout.contiguous()
         if bn is not None and not train_bn:
             raise NotImplementedError("backward through an eval-mode BatchNorm is not on the HIP path")
-        if act == L.ACT_PRELU:
+        if lazy:
+            dz = dout       # dA: the mask [scale*y + shift > 0] is applied inside the two BN-backward passes
+        elif act == L.ACT_PRELU:
             dz = torch.empty_like(dout)
             dalpha = torch.zeros(1, dtype=torch.float32, device=dev)
             L.check(lib.oct_affine_prelu_bwd(e.dt, dout.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
@@ -208,8 +237,11 @@ class ConvAffineAct(torch.autograd.Function):
             # sums of dz and dz*xhat: the reduction kernel of the fused path with its ReLU mask held open
             nblk = lib.oct_dact_bn_reduce_blocks(n, h, wd, cout, 0)
             partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
-            ones, zeros = torch.ones(cout, dtype=torch.float32, device=dev), torch.zeros(cout, dtype=torch.float32, device=dev)
-            L.check(lib.oct_dact_bn_reduce(e.dt, dz.data_ptr(), None, y.data_ptr(), zeros.data_ptr(), ones.data_ptr(),
+            if lazy:
+                msc, msh = scale, shift
+            else:       # dz is already masked: hold the reduction kernel's ReLU mask open (0*y + 1 > 0)
+                msc, msh = e._const(0.0, cout, dev), e._const(1.0, cout, dev)
+            L.check(lib.oct_dact_bn_reduce(e.dt, dz.data_ptr(), None, y.data_ptr(), msc.data_ptr(), msh.data_ptr(),
                                            mean.data_ptr(), invstd.data_ptr(), None, partials.data_ptr(), n, h, wd, cout,
                                            _stream()), "oct_dact_bn_reduce")
             dgamma, dbeta = torch.empty_like(scale), torch.empty_like(scale)
@@ -217,9 +249,11 @@ class ConvAffineAct(torch.autograd.Function):
             L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, cout, float(npix), gamma.data_ptr(),
                                             mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                             coef.data_ptr(), 0, _stream()), "oct_bn_bwd_finalize")
-            dy = dz.clone() if (has_res or dz is dout) else dz
-            L.check(lib.oct_bn_bwd_apply(e.dt, dy.data_ptr(), y.data_ptr(), coef.data_ptr(), None, None, npix, cout,
-                                         _stream()), "oct_bn_bwd_apply")
+            # dz stays intact when somebody else still reads it (the residual branch's gradient, autograd's own buffer)
+            dy = torch.empty_like(dz) if (has_res or dz is dout) else dz
+            L.check(lib.oct_bn_bwd_apply_to(e.dt, dy.data_ptr(), dz.data_ptr(), y.data_ptr(), coef.data_ptr(),
+                                            scale.data_ptr() if lazy else None, shift.data_ptr() if lazy else None,
+                                            npix, cout, _stream()), "oct_bn_bwd_apply_to")
             if has_bias:
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
         else:
@@ -233,7 +267,7 @@ class ConvAffineAct(torch.autograd.Function):
                 dcb = torch.empty(cout, dtype=torch.float32, device=dev)
                 L.check(lib.oct_channel_sum(e.dt, dy.data_ptr(), dcb.data_ptr(), npix, cout, 0, _stream()),
                         "oct_channel_sum")
-        src = Src(x0, c0, None, x1, c1, None)
+        src = Src(x0, c0, BNState(*xf0) if xf0 else None, x1, c1, BNState(*xf1) if xf1 else None)
         dwp = e._wgrad(src, dy, cout, taps, n, h, wd, dbias=dcb if fuse_bias else None, **kd)
         dw = torch.empty_like(w)
         if kk:
@@ -247,7 +281,7 @@ class ConvAffineAct(torch.autograd.Function):
             d0 = e._act(n, h, wd, c0, dev)
             d1 = e._act(n, h, wd, c1, dev) if c1 else None
             e._conv(Src(dy, cout), wp, cin, taps, n, h, wd, d0, y1=d1, split=c0 if c1 else 0, **kd)
-        return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres, dalpha
+        return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres, dalpha, None, None, None
 
 
 class MaxPool(torch.autograd.Function):
@@ -459,16 +493,48 @@ class Gate(torch.autograd.Function):
 
 
 # ---- functional spellings -----------------------------------------------------------------------
-def conv_bn_act(dtype, x0, conv, bn=None, act=L.ACT_NONE, x1=None, res=None, prelu=None):
+def conv_bn_act(dtype, x0, conv, bn=None, act=L.ACT_NONE, x1=None, res=None, prelu=None, lazy=False):
     """conv: nn.Conv2d container (3x3 pad 1, 1x1, or 7x3 pad (3,1)); bn: nn.BatchNorm2d container or None;
-    prelu: nn.PReLU container (num_parameters 1) -> act becomes PReLU."""
+    prelu: nn.PReLU container (num_parameters 1) -> act becomes PReLU.
+    x0 / x1 may be LazyAct (BN + ReLU applied on load); lazy=True returns one (only for a consumer that is a
+    convolution; falls back to the materialised tensor when BN is in eval mode or the 7x3 / fp32 kernels would run)."""
     if prelu is not None:
         if prelu.weight.numel() != 1:
             raise NotImplementedError("per-channel PReLU is not on the HIP path (the reference uses nn.PReLU())")
         act = L.ACT_PRELU
-    return ConvAffineAct.apply(dtype, bn, act, x0, x1, conv.weight, conv.bias,
-                               bn.weight if bn is not None else None, bn.bias if bn is not None else None, res,
-                               prelu.weight if prelu is not None else None)
+    xf0 = xf1 = None
+    if isinstance(x0, LazyAct):
+        x0, xf0 = x0.y, (x0.scale, x0.shift)
+    if isinstance(x1, LazyAct):
+        x1, xf1 = x1.y, (x1.scale, x1.shift)
+    lazy = bool(lazy and bn is not None and bn.training and act == L.ACT_RELU and res is None
+                and tuple(conv.weight.shape[2:]) in ((1, 1), (3, 3)))
+    r = ConvAffineAct.apply(dtype, bn, act, x0, x1, conv.weight, conv.bias,
+                            bn.weight if bn is not None else None, bn.bias if bn is not None else None, res,
+                            prelu.weight if prelu is not None else None, xf0, xf1, lazy)
+    return LazyAct(*r) if lazy else r
+
+
+def materialise(dtype, a):
+    """LazyAct -> the activated NHWC tensor (for a consumer that is not a convolution); tensors pass through."""
+    if not isinstance(a, LazyAct):
+        return a
+    return _Materialise.apply(dtype, a.y, a.scale, a.shift)
+
+
+class _Materialise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dtype, y, scale, shift):
+        e = kernels(dtype)
+        n, h, w, c = y.shape
+        out = e._act(n, h, w, c, y.device)
+        L.check(L.lib().oct_affine_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, L.ACT_RELU,
+                                           out.data_ptr(), n * h * w, c, _stream()), "oct_affine_act_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return None, dout, None, None      # the producer's backward takes dA and masks it itself
 
 
 def to_nhwc(x, dtype):

@@ -9,7 +9,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]
 print("\nrocprofv3 --kernel-trace --stats (kernel durations only):")
 n = 32 * 512 * 1024
-byt = [("confusion_u8", 2 * n), ("class_confusion_kernel<unsigned char>", 2 * n), ("class_confusion_kernel<long>", 16 * n),
+byt = [("confusion_u8", 2 * n), ("class_confusion_kernel<unsigned char", 2 * n), ("class_confusion_kernel<long", 16 * n),
        (" confusion_kernel<long", 16 * n), ("sqdiff", 2 * n), ("column_absdiff", 2 * n)]
 for r in csv.DictReader(open(f)):
     for k, b in byt:
