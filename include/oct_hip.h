@@ -44,6 +44,7 @@ extern "C" {
 /* source transform applied while a conv stages its input (BN-apply + ReLU fused on load) */
 #define OCT_XF_NONE 0
 #define OCT_XF_AFFINE_RELU 1 /* a = max(x*scale[c] + shift[c], 0) */
+#define OCT_XF_AFFINE 2      /* a = x*scale[c] + shift[c]: a deferred bias add (SD_Layer_Net conv_block.init_conv) */
 
 /* input / output addressing of the implicit GEMM */
 #define OCT_IN_PLAIN 0
@@ -249,6 +250,21 @@ int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const
  * residual branch of SD_Layer_Net's conv_block, common.py:22-25 -- needs no copy first). dst == g is allowed.   */
 int oct_bn_bwd_apply_to(int dtype, void* dst, const void* g, const void* y, const float* coef, const float* scale,
                         const float* shift, size_t npix, int c, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * 1x1 convolution with ONE output channel: Attention_block's psi = Conv2d(F_int, 1, 1) (SD_Layer_Net/common.py:79-83).
+ * Three streaming kernels instead of GEMMs padded 1 -> 32 (c = 8 * 2^k <= 512: oct_rowdot_ok; other widths stay on
+ * oct_conv_forward / oct_conv_wgrad).  x, dx: [npix][c] NHWC; y, dy: [npix]; w, dw: [c] fp32 (torch (1,c,1,1)).
+ *   fwd       : y = x . w; stats (may be NULL): [oct_rowdot_blocks][2][1] partial sum / sum of squares (oct_bn_finalize rows)
+ *   bwd_data  : dx[pix][c] = dy[pix] * w[c]
+ *   bwd_weight: dw[c] (+)= sum_pix dy[pix] * x[pix][c]; partials: scratch [oct_rowdot_blocks][c], summed in block order
+ * ------------------------------------------------------------------------------------------ */
+int oct_rowdot_ok(int c);
+int oct_rowdot_blocks(size_t npix, int c);
+int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y, float* stats, size_t npix, int c, void* stream);
+int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, void* dx, size_t npix, int c, void* stream);
+int oct_rowdot_bwd_weight(int dtype, const void* dy, const void* x, float* dw, float* partials, size_t npix, int c,
+                          int accumulate, void* stream);
+
 /* per-channel sum over pixels of an NHWC tensor (bias gradient of ConvTranspose2d) */
 int oct_channel_sum(int dtype, const void* x, float* out, size_t npix, int c, int accumulate,
                     void* stream);
@@ -328,6 +344,10 @@ int oct_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float
  * `conv(x) + init_conv` + act (common.py:21-25), BN+Sigmoid (common.py:77-81).  res may be NULL. */
 int oct_affine_act_fwd(int dtype, const void* y, const float* scale, const float* shift,
                        const void* res, int act, void* out, size_t npix, int c, void* stream);
+/* The same with a residual whose bias add was deferred (OCT_XF_AFFINE producer): out = act(scale*y + shift + T(res + res_shift[c])),
+ * the sum rounded to the storage type first -- bit-identical to a residual that had been materialised.            */
+int oct_affine_res_act_fwd(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                           const float* res_shift, int act, void* out, size_t npix, int c, void* stream);
 /* dz = dout * act'(z), from the stored output: relu [out>0], sigmoid out*(1-out). dz may alias dout */
 int oct_act_bwd(int dtype, const void* dout, const void* out, int act, void* dz, size_t n, void* stream);
 /* nn.MaxPool2d(k) on a materialised activation (SD_Layer_Net/unet.py:85, MGUNet_2021.py:211-217);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OCT_HIP_LIB") or os.path.join(PKG_DIR, "liboct_hip.so
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 DT_BF16, DT_F32 = 0, 1
-XF_NONE, XF_AFFINE_RELU = 0, 1
+XF_NONE, XF_AFFINE_RELU, XF_AFFINE = 0, 1, 2
 IN_PLAIN, IN_S2D = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ACT_PRELU = 3   # host-side tag only: PReLU has its own entry points (oct_affine_prelu_fwd / _bwd)
@@ -114,6 +114,11 @@ SIGNATURES = {
     "oct_bn_bwd_apply_to": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                     c_void_p]),
     "oct_channel_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "oct_rowdot_ok": (c_int, [c_int]),
+    "oct_rowdot_blocks": (c_int, [c_size_t, c_int]),
+    "oct_rowdot_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oct_rowdot_bwd_data": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oct_rowdot_bwd_weight": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "oct_head_blocks": (c_int, [C.POINTER(HeadDesc)]),
     "oct_head_forward": (c_int, [C.POINTER(HeadDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -130,6 +135,8 @@ SIGNATURES = {
                              c_void_p]),
     "oct_affine_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int,
                                    c_void_p]),
+    "oct_affine_res_act_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                       c_int, c_void_p]),
     "oct_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "oct_maxpool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_maxpool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

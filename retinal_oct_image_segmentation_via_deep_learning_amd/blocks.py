@@ -177,7 +177,8 @@ class conv_block(HipModule):
         """a / a1: NHWC tensors or ops.LazyAct (BN + ReLU of the producer applied on load)."""
         _check_dropout(self)
         dt = self.compute_dtype
-        i = ops.conv_bn_act(dt, a, self.init_conv, x1=a1)
+        # init_conv's bias add is deferred too: the next convolution and the residual sum apply it (OCT_XF_AFFINE)
+        i = ops.conv_bn_act(dt, a, self.init_conv, x1=a1, lazy=True)
         # relu(bn(conv0(i))) has one consumer, a convolution: it is never written (deferred activation)
         t = ops.conv_bn_act(dt, i, self.conv[0], self.conv[1], L.ACT_RELU, lazy=True)
         return ops.conv_bn_act(dt, t, self.conv[4], self.conv[5], L.ACT_RELU, res=i)
@@ -266,6 +267,7 @@ class _SDUNetBase(HipModule):
             # the reference fails at torch.cat((x4, d5), dim=1) (unet.py:55,130) for such sizes
             raise RuntimeError(f"Sizes of tensors must match except in dimension 1. Input {x.shape[2]}x{x.shape[3]} "
                                f"is not divisible by {div}")
+        ops.prepack(self.compute_dtype, self)
         feats = self._encode(self._in(x))
         d = feats[-1]
         for i in range(self._levels, 1, -1):

@@ -34,8 +34,8 @@ __device__ __forceinline__ float act_apply(float z, int act) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int V>
 __global__ void affine_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
-                                      const float* __restrict__ shift, const T* __restrict__ res, int act,
-                                      T* __restrict__ out, size_t npix, int c) {
+                                      const float* __restrict__ shift, const T* __restrict__ res,
+                                      const float* __restrict__ res_shift, int act, T* __restrict__ out, size_t npix, int c) {
   const int G = c / V;
   const size_t total = npix * G;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -43,24 +43,37 @@ __global__ void affine_act_fwd_kernel(const T* __restrict__ y, const float* __re
     float sc[V], sh[V], v[V], r[V];
     load_vec<float, V>(scale + g * V, sc); load_vec<float, V>(shift + g * V, sh);
     load_vec<T, V>(y + off, v);
-    if (res) load_vec<T, V>(res + off, r);
+    if (res) {
+      load_vec<T, V>(res + off, r);
+      if (res_shift) {   // the residual's deferred bias: (r + b) in the storage type first, as if it had been materialised
+        float rb[V];
+        load_vec<float, V>(res_shift + g * V, rb);
+#pragma unroll
+        for (int j = 0; j < V; ++j) r[j] = to_f32(from_f32<T>(r[j] + rb[j]));
+      }
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) v[j] = act_apply(fmaf(v[j], sc[j], sh[j]) + (res ? r[j] : 0.f), act);
     store_vec<T, V>(out + off, v);
   }
 }
-extern "C" int oct_affine_act_fwd(int dtype, const void* y, const float* scale, const float* shift, const void* res,
-                                  int act, void* out, size_t npix, int c, void* stream) {
+extern "C" int oct_affine_res_act_fwd(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                                      const float* res_shift, int act, void* out, size_t npix, int c, void* stream) {
   OCT_CHECK(y && scale && shift && out && npix > 0 && c > 0, "oct_affine_act_fwd: bad args");
+  OCT_CHECK(res || !res_shift, "oct_affine_act_fwd: res_shift without a residual");
   OCT_CHECK(act >= OCT_ACT_NONE && act <= OCT_ACT_SIGMOID, "oct_affine_act_fwd: bad activation %d", act);
   const int v = bk_vec(c);
   const int blocks = bk_blocks(npix * (c / v));
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T, V) hipLaunchKernelGGL((affine_act_fwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, \
-                                        (const T*)y, scale, shift, (const T*)res, act, (T*)out, npix, c)
+                                        (const T*)y, scale, shift, (const T*)res, res_shift, act, (T*)out, npix, c)
   BK_DISPATCH("oct_affine_act_fwd");
 #undef LAUNCH
   return oct_check_launch("affine_act_fwd");
+}
+extern "C" int oct_affine_act_fwd(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                                  int act, void* out, size_t npix, int c, void* stream) {
+  return oct_affine_res_act_fwd(dtype, y, scale, shift, res, nullptr, act, out, npix, c, stream);
 }
 
 // dz = dout * act'(out) expressed through the stored output: relu -> [out > 0], sigmoid -> out (1 - out)
@@ -619,4 +632,176 @@ extern "C" int oct_depth_pool_bwd(int dtype, const void* p2, const void* dout, v
   BK_DISPATCH("oct_depth_pool_bwd");
 #undef LAUNCH
   return oct_check_launch("depth_pool_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolution with ONE output channel -- Attention_block's psi (common.py:79-83: Conv2d(F_int, 1, 1)):
+//   y[pix] = sum_c x[pix][c] * w[c],  dx[pix][c] = dy[pix] * w[c],  dw[c] = sum_pix dy[pix] * x[pix][c].
+// On the MFMA kernels that is a GEMM with 31 of 32 output rows (or K lanes) padded: 3.8 ms per cfg4 step for what is
+// three streaming passes over the F_int-channel tensor (0.7 GB each).  G = c/8 lanes share a pixel (16-B loads /
+// stores), the dot product closes with log2(G) shuffles.  bf16 mode rounds the weight to bf16 first, like the packed
+// MFMA operand it replaces; sums are fp32.
+// ---------------------------------------------------------------------------------------------
+#define RD_MAX_BLOCKS 512
+static inline bool rowdot_shape_ok(int c) { const int g = c / 8; return c % 8 == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0; }
+static inline int rowdot_grid(size_t npix, int c) {
+  const size_t ppb = BK_THREADS / (c / 8);
+  size_t b = (npix + 4 * ppb - 1) / (4 * ppb);
+  if (b > RD_MAX_BLOCKS) b = RD_MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+extern "C" int oct_rowdot_ok(int c) { return rowdot_shape_ok(c) ? 1 : 0; }
+extern "C" int oct_rowdot_blocks(size_t npix, int c) { return rowdot_shape_ok(c) ? rowdot_grid(npix, c) : 0; }
+
+template <typename T> __device__ __forceinline__ float rd_round(float v) { return to_f32(from_f32<T>(v)); }
+
+template <typename T>
+__global__ void __launch_bounds__(BK_THREADS) rowdot_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                                float* __restrict__ stats, size_t npix, int c) {
+  const int G = c / 8, gi = threadIdx.x % G, slot = threadIdx.x / G, ppb = BK_THREADS / G;
+  float wv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wv[j] = rd_round<T>(w[gi * 8 + j]);
+  float s1 = 0.f, s2 = 0.f;
+  const size_t stride = (size_t)gridDim.x * ppb;
+  auto finish = [&](float d, size_t pix) {
+    for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
+    if (gi == 0) { y[pix] = from_f32<T>(d); s1 += d; s2 = fmaf(d, d, s2); }
+  };
+  size_t pix = (size_t)blockIdx.x * ppb + slot;
+  for (; pix + 3 * stride < npix; pix += 4 * stride) {   // four pixels in flight per lane
+    float xv[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_vec_nt<T, 8>(x + (pix + u * stride) * c + gi * 8, xv[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d = fmaf(xv[u][j], wv[j], d);
+      finish(d, pix + u * stride);
+    }
+  }
+  for (; pix < npix; pix += stride) {
+    float xv[8];
+    load_vec<T, 8>(x + pix * c + gi * 8, xv);
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d = fmaf(xv[j], wv[j], d);
+    finish(d, pix);
+  }
+  if (stats) {   // one row [2][1] per workgroup, the layout oct_bn_finalize reads
+    __shared__ float red[2][BK_THREADS / 64];
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 2) stats[(size_t)blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BK_THREADS) rowdot_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                                     T* __restrict__ dx, size_t npix, int c) {
+  const int G = c / 8, gi = threadIdx.x % G, slot = threadIdx.x / G, ppb = BK_THREADS / G;
+  float wv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wv[j] = rd_round<T>(w[gi * 8 + j]);
+  const size_t stride = (size_t)gridDim.x * ppb;
+  for (size_t pix = (size_t)blockIdx.x * ppb + slot; pix < npix; pix += stride) {
+    const float g = to_f32(dy[pix]);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = g * wv[j];
+    store_vec_nt<T, 8>(dx + pix * c + gi * 8, o);
+  }
+}
+
+// per-workgroup partial rows part[block][c] (plain stores), summed in block order by rowdot_bwd_weight_sum_kernel:
+// the weight gradient is bit-reproducible from run to run
+template <typename T>
+__global__ void __launch_bounds__(BK_THREADS) rowdot_bwd_weight_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                       float* __restrict__ part, size_t npix, int c) {
+  const int G = c / 8, gi = threadIdx.x % G, slot = threadIdx.x / G, ppb = BK_THREADS / G;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const size_t stride = (size_t)gridDim.x * ppb;
+  size_t pix = (size_t)blockIdx.x * ppb + slot;
+  for (; pix + 3 * stride < npix; pix += 4 * stride) {
+    float xv[4][8], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { load_vec_nt<T, 8>(x + (pix + u * stride) * c + gi * 8, xv[u]); g[u] = to_f32(dy[pix + u * stride]); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(g[u], xv[u][j], acc[j]);
+  }
+  for (; pix < npix; pix += stride) {
+    float xv[8];
+    load_vec<T, 8>(x + pix * c + gi * 8, xv);
+    const float g = to_f32(dy[pix]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, xv[j], acc[j]);
+  }
+  // lanes gi, gi + G, gi + 2G ... of a wave own the same channels: fold them, then the four waves through LDS
+  __shared__ float red[BK_THREADS / 64][512];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = acc[j];
+    for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) < G) red[threadIdx.x >> 6][gi * 8 + j] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += BK_THREADS) part[(size_t)blockIdx.x * c + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+// 16 channels x 16 row-slices per workgroup; slice s adds rows s, s + 16, ... in order, the slices are folded in order:
+// a fixed summation tree (reproducible), 32 dependent loads per thread instead of 512
+__global__ void __launch_bounds__(256) rowdot_bwd_weight_sum_kernel(const float* __restrict__ part, int nblk, int c,
+                                                                    float* __restrict__ dw, int accumulate) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, i = blockIdx.x * 16 + cl;
+  float v = 0.f;
+  if (i < c)
+    for (int b = sl; b < nblk; b += 16) v += part[(size_t)b * c + i];
+  red[sl][cl] = v;
+  __syncthreads();
+  if (sl == 0 && i < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
+}
+
+extern "C" int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y, float* stats, size_t npix, int c, void* stream) {
+  OCT_CHECK(x && w && y && npix > 0, "oct_rowdot_fwd: bad args");
+  OCT_CHECK(rowdot_shape_ok(c), "oct_rowdot_fwd: c = %d must be 8 * 2^k, at most 512 (ask oct_rowdot_ok)", c);
+  const int grid = rowdot_grid(npix, c);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OCT_DT_BF16) hipLaunchKernelGGL(rowdot_fwd_kernel<bf16_t>, dim3(grid), dim3(BK_THREADS), 0, s, (const bf16_t*)x, w, (bf16_t*)y, stats, npix, c);
+  else if (dtype == OCT_DT_F32) hipLaunchKernelGGL(rowdot_fwd_kernel<float>, dim3(grid), dim3(BK_THREADS), 0, s, (const float*)x, w, (float*)y, stats, npix, c);
+  else OCT_CHECK(false, "oct_rowdot_fwd: bad dtype");
+  return oct_check_launch("rowdot_fwd");
+}
+extern "C" int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, void* dx, size_t npix, int c, void* stream) {
+  OCT_CHECK(dy && w && dx && npix > 0, "oct_rowdot_bwd_data: bad args");
+  OCT_CHECK(rowdot_shape_ok(c), "oct_rowdot_bwd_data: c = %d must be 8 * 2^k, at most 512", c);
+  const int grid = rowdot_grid(npix, c);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OCT_DT_BF16) hipLaunchKernelGGL(rowdot_bwd_data_kernel<bf16_t>, dim3(grid), dim3(BK_THREADS), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, npix, c);
+  else if (dtype == OCT_DT_F32) hipLaunchKernelGGL(rowdot_bwd_data_kernel<float>, dim3(grid), dim3(BK_THREADS), 0, s, (const float*)dy, w, (float*)dx, npix, c);
+  else OCT_CHECK(false, "oct_rowdot_bwd_data: bad dtype");
+  return oct_check_launch("rowdot_bwd_data");
+}
+extern "C" int oct_rowdot_bwd_weight(int dtype, const void* dy, const void* x, float* dw, float* partials, size_t npix, int c,
+                                     int accumulate, void* stream) {
+  OCT_CHECK(dy && x && dw && partials && npix > 0, "oct_rowdot_bwd_weight: bad args");
+  OCT_CHECK(rowdot_shape_ok(c), "oct_rowdot_bwd_weight: c = %d must be 8 * 2^k, at most 512", c);
+  const int grid = rowdot_grid(npix, c);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OCT_DT_BF16) hipLaunchKernelGGL(rowdot_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(BK_THREADS), 0, s, (const bf16_t*)dy, (const bf16_t*)x, partials, npix, c);
+  else if (dtype == OCT_DT_F32) hipLaunchKernelGGL(rowdot_bwd_weight_kernel<float>, dim3(grid), dim3(BK_THREADS), 0, s, (const float*)dy, (const float*)x, partials, npix, c);
+  else OCT_CHECK(false, "oct_rowdot_bwd_weight: bad dtype");
+  hipLaunchKernelGGL(rowdot_bwd_weight_sum_kernel, dim3((c + 15) / 16), dim3(256), 0, s, partials, grid, c, dw, accumulate);
+  return oct_check_launch("rowdot_bwd_weight");
 }

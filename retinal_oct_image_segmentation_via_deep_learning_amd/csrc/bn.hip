@@ -624,6 +624,48 @@ __global__ void channel_sum_kernel(const T* __restrict__ x, float* out, size_t n
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(&out[i], acc[i]);
 }
+// c % 8 == 0 with c/8 dividing the workgroup: a lane owns one 8-channel group for the whole kernel (16-B loads, four
+// in flight), folds with the lanes that share its group, one LDS row per wave, one atomic per channel and workgroup.
+// The element-per-thread kernel above read 2 B per lane and instruction: 1.2 TB/s on a 0.8 GB tensor.
+template <typename T>
+__global__ void __launch_bounds__(EW_THREADS) channel_sum_flat_kernel(const T* __restrict__ x, float* out, size_t total /* groups */, int c) {
+  constexpr int V = 8;
+  const int G = c / V, gi = threadIdx.x % G;
+  __shared__ float red[EW_THREADS / 64][512];
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  const size_t stride = (size_t)gridDim.x * EW_THREADS;
+  size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  for (; i + 3 * stride < total; i += 4 * stride) {
+    float v[4][V];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_vec_nt<T, V>(x + (i + u * stride) * V, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += v[u][j];
+  }
+  for (; i < total; i += stride) {
+    float v[V];
+    ldv<T, V>(x + i * V, v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] += v[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {   // G <= 64 (c <= 512): the lanes gi, gi + G, ... of a wave share the group
+    float v = acc[j];
+    for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    if (lane < G) red[wave][gi * V + j] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < c; k += EW_THREADS) {
+    float v = 0.f;
+    for (int w_ = 0; w_ < EW_THREADS / 64; ++w_) v += red[w_][k];
+    atomicAdd(&out[k], v);
+  }
+}
 __global__ void zero_f32_kernel(float* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
 }
@@ -634,6 +676,18 @@ extern "C" int oct_channel_sum(int dtype, const void* x, float* out, size_t npix
   size_t b = (npix * c + 256 * 64 - 1) / (256 * 64);
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
+  if (c % 8 == 0 && c <= 512 && ((c / 8) & (c / 8 - 1)) == 0 && lane_mapping_ok(c, 8) && (((uintptr_t)x) & 15) == 0) {
+    const size_t total = npix * (size_t)(c / 8);
+    size_t fb = (total + 4 * EW_THREADS - 1) / (4 * EW_THREADS);
+    if (fb > 512) fb = 512;
+    if (dtype == OCT_DT_BF16)
+      hipLaunchKernelGGL(channel_sum_flat_kernel<bf16_t>, dim3((int)fb), dim3(EW_THREADS), 0, s, (const bf16_t*)x, out, total, c);
+    else if (dtype == OCT_DT_F32)
+      hipLaunchKernelGGL(channel_sum_flat_kernel<float>, dim3((int)fb), dim3(EW_THREADS), 0, s, (const float*)x, out, total, c);
+    else
+      OCT_CHECK(false, "oct_channel_sum: bad dtype");
+    return oct_check_launch("channel_sum_flat");
+  }
   if (dtype == OCT_DT_BF16)
     hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3((int)b), dim3(256), c * sizeof(float), s, (const bf16_t*)x, out, npix, c);
   else if (dtype == OCT_DT_F32)

@@ -32,6 +32,9 @@ int oct_first_stat_rows(const OctConvDesc* d);
 int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream);
 int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query = nullptr);
 
+// lower clamp of the on-load transform a = max(x*scale + shift, floor): 0 for BN + ReLU (OCT_XF_AFFINE_RELU), -inf for the
+// plain per-channel affine (OCT_XF_AFFINE: a deferred bias add) -- the same v_max either way
+__device__ __forceinline__ float xf_floor(int xf) { return xf == 2 ? -__builtin_inff() : 0.f; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);

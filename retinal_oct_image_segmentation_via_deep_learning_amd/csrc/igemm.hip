@@ -39,7 +39,7 @@ __device__ __forceinline__ float fetch1(const IgemmParams& p, int img, int iy, i
     if (p.depth > 0) { img = 2 * img + (dydx >> 2); dydx &= 3; }
     const size_t pix = ((size_t)img * (2 * p.h) + (2 * iy + (dydx >> 1))) * (size_t)(2 * p.w) + (2 * ix + (dydx & 1));
     float v = to_f32(reinterpret_cast<const T*>(p.x0)[pix * p.c0 + c]);
-    if (p.xf0) v = fmaxf(fmaf(v, p.sc0[c], p.sh0[c]), 0.f);
+    if (p.xf0) v = fmaxf(fmaf(v, p.sc0[c], p.sh0[c]), xf_floor(p.xf0));
     return v;
   }
   if (p.depth > 0) {
@@ -52,12 +52,12 @@ __device__ __forceinline__ float fetch1(const IgemmParams& p, int img, int iy, i
   const size_t pix = ((size_t)img * p.h + iy) * (size_t)p.w + ix;
   if (k < p.c0) {
     float v = to_f32(reinterpret_cast<const T*>(p.x0)[pix * p.c0 + k]);
-    if (p.xf0) v = fmaxf(fmaf(v, p.sc0[k], p.sh0[k]), 0.f);
+    if (p.xf0) v = fmaxf(fmaf(v, p.sc0[k], p.sh0[k]), xf_floor(p.xf0));
     return v;
   }
   const int c = k - p.c0;
   float v = to_f32(reinterpret_cast<const T*>(p.x1)[pix * p.c1 + c]);
-  if (p.xf1) v = fmaxf(fmaf(v, p.sc1[c], p.sh1[c]), 0.f);
+  if (p.xf1) v = fmaxf(fmaf(v, p.sc1[c], p.sh1[c]), xf_floor(p.xf1));
   return v;
 }
 
@@ -65,6 +65,7 @@ template <typename T>
 __device__ __forceinline__ void fetch8(const IgemmParams& p, int img, int iy, int ix, int k, float (&v)[8]) {
   // fast paths: the 8-group lies inside one source and is 8-aligned there
   const T* src = nullptr; const float* sc = nullptr; const float* sh = nullptr; int c = 0; int cs = 0; bool xf = false;
+  float lo = 0.f;   // clamp of the transform (xf_floor)
   size_t pix = 0;
   if (p.in_mode == OCT_IN_S2D) {
     if ((p.c0 & 7) == 0 && k + 8 <= p.ktot) {
@@ -72,7 +73,7 @@ __device__ __forceinline__ void fetch8(const IgemmParams& p, int img, int iy, in
       int im = img;
       if (p.depth > 0) { im = 2 * img + (dydx >> 2); dydx &= 3; }
       pix = ((size_t)im * (2 * p.h) + (2 * iy + (dydx >> 1))) * (size_t)(2 * p.w) + (2 * ix + (dydx & 1));
-      src = reinterpret_cast<const T*>(p.x0); sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0;
+      src = reinterpret_cast<const T*>(p.x0); sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0; lo = xf_floor(p.xf0);
     }
   } else if (p.depth > 0 && ((p.csrc & 7) != 0 || k + 8 > p.ktot)) {
     // depth taps on a channel count that is not a multiple of 8 (the 1-channel input volume): element by element
@@ -92,9 +93,9 @@ __device__ __forceinline__ void fetch8(const IgemmParams& p, int img, int iy, in
     const int k = kk;   // channel inside the (virtually concatenated) source of this depth tap
     pix = ((size_t)im * p.h + iy) * (size_t)p.w + ix;
     if ((p.c0 & 7) == 0 && k + 8 <= p.c0) {
-      src = reinterpret_cast<const T*>(p.x0); c = k; cs = p.c0; sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0;
+      src = reinterpret_cast<const T*>(p.x0); c = k; cs = p.c0; sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0; lo = xf_floor(p.xf0);
     } else if ((p.c0 & 7) == 0 && (p.c1 & 7) == 0 && k >= p.c0 && k + 8 <= p.c0 + p.c1) {
-      src = reinterpret_cast<const T*>(p.x1); c = k - p.c0; cs = p.c1; sc = p.sc1; sh = p.sh1; xf = p.xf1 != 0;
+      src = reinterpret_cast<const T*>(p.x1); c = k - p.c0; cs = p.c1; sc = p.sc1; sh = p.sh1; xf = p.xf1 != 0; lo = xf_floor(p.xf1);
     }
   }
   if (src) {
@@ -106,7 +107,7 @@ __device__ __forceinline__ void fetch8(const IgemmParams& p, int img, int iy, in
       load_vec<float, 4>(sh + c, reinterpret_cast<float(&)[4]>(b[0]));
       load_vec<float, 4>(sh + c + 4, reinterpret_cast<float(&)[4]>(b[4]));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], s[j], b[j]), 0.f);
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], s[j], b[j]), lo);
     }
   } else {
 #pragma unroll
@@ -548,6 +549,7 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
   OCT_CHECK(!(d->out_mode == OCT_OUT_D2S && (d->cout & 3)), "oct_conv_forward: D2S needs cout %% 4 == 0");
   OCT_CHECK(d->split >= 0 && d->split < d->cout, "oct_conv_forward: bad split %d", d->split);
   OCT_CHECK(d->split == 0 || a->y1, "oct_conv_forward: split without y1");
+  OCT_CHECK(d->xform0 >= 0 && d->xform0 <= OCT_XF_AFFINE && d->xform1 >= 0 && d->xform1 <= OCT_XF_AFFINE, "oct_conv_forward: bad xform");
   OCT_CHECK(!(d->xform0 && (!a->scale0 || !a->shift0)), "oct_conv_forward: xform0 without scale/shift");
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_forward: xform1 without scale/shift");
   OCT_CHECK(!(d->want_stats && !a->stat_partials), "oct_conv_forward: want_stats without buffer");

@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // two kernel arguments would become a VECTOR load + s_waitcnt vmcnt(0) in the middle of the ring
       const bool first = s2d || chc * 32 < p.c0;
       const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
+      const float flo = xf_floor(first ? p.xf0 : p.xf1);   // wave-uniform: 0 (BN + ReLU) or -inf (plain affine)
       float s[8], b[8];
       if (xf) {
         const int kx = s2d ? p.c0 : p.c0 + p.c1;
@@ -255,8 +256,8 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float lo = fmaxf(fmaf(bf16lo(v[j]), s[2 * j], b[2 * j]), 0.f);
-              const float hi = fmaxf(fmaf(bf16hi(v[j]), s[2 * j + 1], b[2 * j + 1]), 0.f);
+              const float lo = fmaxf(fmaf(bf16lo(v[j]), s[2 * j], b[2 * j]), flo);
+              const float hi = fmaxf(fmaf(bf16hi(v[j]), s[2 * j + 1], b[2 * j + 1]), flo);
               v[j] = pack_bf16x2(lo, hi);
             }
           }

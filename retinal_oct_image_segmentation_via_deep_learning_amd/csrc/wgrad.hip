@@ -31,28 +31,29 @@ __device__ __forceinline__ float wg_fetch_in(const WgradParams& p, size_t pix, i
   if (k >= p.ktot) return 0.f;
   if (k < p.c0) {
     float v = to_f32(reinterpret_cast<const T*>(p.x0)[pix * p.c0 + k]);
-    if (p.xf0) v = fmaxf(fmaf(v, p.sc0[k], p.sh0[k]), 0.f);
+    if (p.xf0) v = fmaxf(fmaf(v, p.sc0[k], p.sh0[k]), xf_floor(p.xf0));
     return v;
   }
   const int c = k - p.c0;
   float v = to_f32(reinterpret_cast<const T*>(p.x1)[pix * p.c1 + c]);
-  if (p.xf1) v = fmaxf(fmaf(v, p.sc1[c], p.sh1[c]), 0.f);
+  if (p.xf1) v = fmaxf(fmaf(v, p.sc1[c], p.sh1[c]), xf_floor(p.xf1));
   return v;
 }
 
 template <typename T>
 __device__ __forceinline__ void wg_fetch_in8(const WgradParams& p, size_t pix, int k, float (&v)[8]) {
   const T* src = nullptr; const float* sc = nullptr; const float* sh = nullptr; int c = 0, cs = 0; bool xf = false;
+  float lo = 0.f;   // clamp of the transform (xf_floor)
   if ((p.c0 & 7) == 0 && k + 8 <= p.c0) {
-    src = reinterpret_cast<const T*>(p.x0); c = k; cs = p.c0; sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0;
+    src = reinterpret_cast<const T*>(p.x0); c = k; cs = p.c0; sc = p.sc0; sh = p.sh0; xf = p.xf0 != 0; lo = xf_floor(p.xf0);
   } else if ((p.c0 & 7) == 0 && (p.c1 & 7) == 0 && k >= p.c0 && k + 8 <= p.ktot) {
-    src = reinterpret_cast<const T*>(p.x1); c = k - p.c0; cs = p.c1; sc = p.sc1; sh = p.sh1; xf = p.xf1 != 0;
+    src = reinterpret_cast<const T*>(p.x1); c = k - p.c0; cs = p.c1; sc = p.sc1; sh = p.sh1; xf = p.xf1 != 0; lo = xf_floor(p.xf1);
   }
   if (src) {
     load_vec<T, 8>(src + pix * cs + c, v);
     if (xf) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[c + j], sh[c + j]), 0.f);
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[c + j], sh[c + j]), lo);
     }
   } else {
 #pragma unroll
@@ -217,6 +218,7 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
   OCT_CHECK(a->x0 && a->dy && a->dwp, "oct_conv_wgrad: null tensor");
   OCT_CHECK(d->c1 == 0 || a->x1, "oct_conv_wgrad: c1 > 0 but x1 is null");
   OCT_CHECK(!(d->dy_mode == OCT_IN_S2D && (d->cout & 3)), "oct_conv_wgrad: S2D dy needs cout %% 4 == 0");
+  OCT_CHECK(d->xform0 >= 0 && d->xform0 <= OCT_XF_AFFINE && d->xform1 >= 0 && d->xform1 <= OCT_XF_AFFINE, "oct_conv_wgrad: bad xform");
   OCT_CHECK(!(d->xform0 && (!a->scale0 || !a->shift0)), "oct_conv_wgrad: xform0 without scale/shift");
   OCT_CHECK(!(d->xform1 && (!a->scale1 || !a->shift1)), "oct_conv_wgrad: xform1 without scale/shift");
   OCT_CHECK(!d->partials || !a->dbias || a->dbias_partials, "oct_conv_wgrad: partials mode with a bias gradient needs dbias_partials");

@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         const int cg = ci_sb + blk * 32;
         const bool second = cg >= p.c0;
         const bool xf = second ? (p.xf1 != 0) : (p.xf0 != 0);
+        const float flo = xf_floor(second ? p.xf1 : p.xf0);   // wave-uniform: 0 (BN + ReLU) or -inf (plain affine)
         float s[8], b[8];
         if (xf) {
           const float* sc = sxf + blk * 32 + g * 8;
@@ -216,8 +217,8 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
             if (xf) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float lo = fmaxf(fmaf(__uint_as_float(v[e] << 16), s[2 * e], b[2 * e]), 0.f);
-                const float hi = fmaxf(fmaf(__uint_as_float(v[e] & 0xffff0000u), s[2 * e + 1], b[2 * e + 1]), 0.f);
+                const float lo = fmaxf(fmaf(__uint_as_float(v[e] << 16), s[2 * e], b[2 * e]), flo);
+                const float hi = fmaxf(fmaf(__uint_as_float(v[e] & 0xffff0000u), s[2 * e + 1], b[2 * e + 1]), flo);
                 v[e] = w2_pack(lo, hi);
               }
             }

@@ -115,6 +115,11 @@ class BNState:
     shift: torch.Tensor
     mean: torch.Tensor | None = None
     invstd: torch.Tensor | None = None
+    relu: bool = True   # False: the consumer applies scale*x + shift without the ReLU (OCT_XF_AFFINE: a deferred bias add)
+
+
+def _xf(bn) -> int:
+    return L.XF_NONE if bn is None else (L.XF_AFFINE_RELU if bn.relu else L.XF_AFFINE)
 
 
 @dataclass
@@ -161,6 +166,8 @@ class UNetEngine:
         self._unpack_jobs = []
         self._nbt = []
         self._consts = {}  # (value, n, device) -> constant fp32 vector (never written)
+        # OCT_ROWDOT=0: one-output-channel 1x1 convolutions stay on the padded MFMA kernels (A/B switch, parity tests)
+        self.rowdot_off = os.environ.get("OCT_ROWDOT", "1") == "0"
         # deterministic = True: weight gradients through the two-stage reduction (OctWgradDesc.partials: per-workgroup slabs
         # summed in order) instead of fp32 atomics -- bit-identical gradients from run to run (OCT_DETERMINISTIC=1 sets it)
         self.deterministic = os.environ.get("OCT_DETERMINISTIC", "0") == "1"
@@ -249,8 +256,7 @@ class UNetEngine:
         """taps 9 / 1 = 3x3 / 1x1; any other kernel passes (kh, kw) and taps = kh*kw (7x3: ReLayNet).
         depth = D > 0: the n images are volumes of D slices and the GEMM gains depth taps (oct_hip.h, OctConvDesc)."""
         d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
-                       L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
-                       L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE,
+                       _xf(src.bn0), _xf(src.bn1),
                        in_mode, out_mode, split, 1 if stats is not None else 0, kh, kw, depth, oimg[0], oimg[1])
         a = L.ConvArgs(L.ptr(src.x0), L.ptr(src.x1),
                        L.ptr(src.bn0.scale) if src.bn0 else None, L.ptr(src.bn0.shift) if src.bn0 else None,
@@ -263,8 +269,7 @@ class UNetEngine:
     def _stat_blocks(self, cout, n, h, w, src: Src, taps=9, kh=0, kw=0, depth=0):
         """rows of the partial-statistics buffer the conv with this exact descriptor will write"""
         d = L.ConvDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
-                       L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
-                       L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, 0, 0, 0, 1, kh, kw, depth, 0, 0)
+                       _xf(src.bn0), _xf(src.bn1), 0, 0, 0, 1, kh, kw, depth, 0, 0)
         return L.lib().oct_conv_stat_blocks(C.byref(d))
 
     def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None, fused_apply=None, kh=0, kw=0,
@@ -275,8 +280,7 @@ class UNetEngine:
         ktot = src.channels
         parts = 1 if (self.deterministic and dwp is None and depth == 0) else 0
         d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
-                        L.XF_AFFINE_RELU if src.bn0 is not None else L.XF_NONE,
-                        L.XF_AFFINE_RELU if src.bn1 is not None else L.XF_NONE, dy_mode, kh, kw, depth, in_shift,
+                        _xf(src.bn0), _xf(src.bn1), dy_mode, kh, kw, depth, in_shift,
                         dy_img[0], dy_img[1], parts)
         bias_parts = None
         if parts:

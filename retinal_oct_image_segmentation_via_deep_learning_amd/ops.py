@@ -12,6 +12,7 @@ There is no CPU fallback: `_lib.lib()` raises when the HIP library is missing.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -19,6 +20,10 @@ from . import _lib as L
 from .engine import BN_EPS, BN_MOMENTUM, BNState, Src, UNetEngine, _stream
 
 _engines: dict = {}
+# OCT_LAZY=0 (or ops.LAZY[0] = False): every activation between ops is materialised -- the A/B switch of the deferred
+# BN + ReLU / bias schedule (LazyAct below); "relu": only the BN + ReLU deferral
+DEBUG = None   # a list: ConvAffineAct.backward appends (tag, tensors) -- probes only
+LAZY = [{"0": False, "relu": "relu"}.get(os.environ.get("OCT_LAZY", "1"), True)]
 
 
 def kernels(dtype: str) -> UNetEngine:
@@ -55,8 +60,31 @@ def packed(e: UNetEngine, w: torch.Tensor, mode: int, cout: int, cin: int, cache
                 "oct_pack_weights_kk")
     else:
         L.check(L.lib().oct_pack_weights(mode, e.dt, w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "oct_pack_weights")
-    store[slot] = (ver, out)
+    store[slot] = (ver, out, cout, cin, kk)
     return out
+
+
+def prepack(dtype: str, module: torch.nn.Module) -> None:
+    """Refresh, in ONE launch, every packed copy an earlier step made of `module`'s weights and the optimizer has since
+    outdated (fprop and dgrad order of ~45 convolutions = 87 five-microsecond launches per AttU_Net step otherwise).
+    The per-op `packed()` calls of the step then all hit the cache."""
+    e = kernels(dtype)
+    jobs, news = [], []
+    for w in module.parameters():
+        store = w.__dict__.get("_oct_packed")
+        if not store:
+            continue
+        ver = (w._version, L.param_generation[0], w.data_ptr())
+        for slot, hit in store.items():
+            if slot[1] != e.dtype or hit[0] == ver or hit[4] is not None or slot[0] > L.PACK_1X1_FPROP:
+                continue
+            jobs.append(L.PackJob(slot[0], hit[2], hit[3], 0, w.data_ptr(), hit[1].data_ptr()))
+            news.append((store, slot, (ver,) + tuple(hit[1:])))
+    if jobs:
+        arr = (L.PackJob * len(jobs))(*jobs)
+        L.check(L.lib().oct_pack_weights_batch(e.dt, len(jobs), arr, _stream()), "oct_pack_weights_batch")
+        for store, slot, val in news:
+            store[slot] = val
 
 
 def _need_cuda(t: torch.Tensor):
@@ -102,13 +130,15 @@ class ToNCHW(torch.autograd.Function):
 
 
 class LazyAct:
-    """relu(scale * y + shift) that is never written: `y` is the raw convolution output and the consumers -- convolutions
-    only -- apply BatchNorm + ReLU while they stage their input (the deferred-activation schedule of `engine.UNetEngine`,
-    here between autograd ops).  Values are bit-identical to the materialised tensor (same fma, same bf16 rounding)."""
-    __slots__ = ("y", "scale", "shift")
+    """act(scale * y + shift) that is never written: `y` is the raw convolution output and the consumers -- convolutions
+    (and the residual input of one) -- apply the per-channel affine while they stage their input: the deferred-activation
+    schedule of `engine.UNetEngine`, here between autograd ops.  relu=True: BatchNorm + ReLU (OCT_XF_AFFINE_RELU);
+    relu=False: scale = 1, shift = the convolution's bias (OCT_XF_AFFINE).  Values are bit-identical to the materialised
+    tensor (same fma, same bf16 rounding)."""
+    __slots__ = ("y", "scale", "shift", "relu")
 
-    def __init__(self, y, scale, shift):
-        self.y, self.scale, self.shift = y, scale, shift
+    def __init__(self, y, scale, shift, relu=True):
+        self.y, self.scale, self.shift, self.relu = y, scale, shift, relu
 
     @property
     def shape(self):
@@ -123,13 +153,16 @@ class ConvAffineAct(torch.autograd.Function):
     bn: the nn.BatchNorm2d container (running buffers are updated in train mode, momentum 0.1).
     A conv bias in front of a train-mode BN only moves the running mean; its gradient is zero.
 
-    xf0 / xf1 = (scale, shift): that input is a LazyAct's raw tensor, BN + ReLU are applied on load (forward, weight
-    gradient) and the data gradient returned for it is the gradient w.r.t. the ACTIVATED tensor.
-    lazy: train-mode BN + ReLU without residual -- return (y, scale, shift) instead of the activated tensor; backward
-    then takes dA, re-derives the ReLU mask from y (no stored activation, no separate mask pass)."""
+    xf0 / xf1 = (scale, shift, relu): that input is a LazyAct's raw tensor, the affine (+ ReLU) is applied on load
+    (forward, weight gradient) and the data gradient returned for it is the gradient w.r.t. the ACTIVATED tensor.
+    lazy = "relu": train-mode BN + ReLU without residual -- return (y, scale, shift) instead of the activated tensor;
+    backward then takes dA, re-derives the ReLU mask from y (no stored activation, no separate mask pass).
+    lazy = "affine": no BN, no activation (a bare convolution with bias) -- return y; the caller pairs it with the bias.
+    res_shift: the residual is a LazyAct(relu=False)'s raw tensor; its bias is folded into this op's shift."""
 
     @staticmethod
-    def forward(ctx, dtype, bn, act, x0, x1, w, cbias, gamma, beta, res, alpha=None, xf0=None, xf1=None, lazy=False):
+    def forward(ctx, dtype, bn, act, x0, x1, w, cbias, gamma, beta, res, alpha=None, xf0=None, xf1=None, lazy=False,
+                res_shift=None):
         e = kernels(dtype)
         lib = L.lib()
         x0 = x0.contiguous()
@@ -148,19 +181,33 @@ class ConvAffineAct(torch.autograd.Function):
         if act == L.ACT_PRELU and (alpha is None or res is not None):
             raise RuntimeError("PReLU needs its slope parameter (and takes no residual)")
         dev = x0.device
-        src = Src(x0, c0, BNState(*xf0) if xf0 else None, x1, c1, BNState(*xf1) if xf1 else None)
-        if lazy and not (bn is not None and bn.training and act == L.ACT_RELU and res is None):
-            raise RuntimeError("a lazy output needs a train-mode BatchNorm + ReLU without residual")
-        wp = packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
+        src = Src(x0, c0, BNState(xf0[0], xf0[1], relu=xf0[2]) if xf0 else None,
+                  x1, c1, BNState(xf1[0], xf1[1], relu=xf1[2]) if xf1 else None)
+        if lazy == "relu" and not (bn is not None and bn.training and act == L.ACT_RELU and res is None):
+            raise RuntimeError("a lazy BN + ReLU output needs a train-mode BatchNorm + ReLU without residual")
+        if lazy == "affine" and not (bn is None and act == L.ACT_NONE and res is None):
+            raise RuntimeError("a lazy affine output is a bare convolution (+ bias)")
+        # one output channel (Attention_block's psi): three streaming kernels instead of GEMMs padded 1 -> 32
+        rowdot = (taps == 1 and cout == 1 and x1 is None and xf0 is None and lib.oct_rowdot_ok(c0) == 1
+                  and not e.rowdot_off)
+        wp = None if rowdot else packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
         y = e._act(n, h, wd, cout, dev)
         scale = torch.empty(cout, dtype=torch.float32, device=dev)
         shift = torch.empty_like(scale)
         mean = invstd = None
         train_bn = bn is not None and bn.training
+
+        def conv(stats=None):
+            if rowdot:
+                L.check(lib.oct_rowdot_fwd(e.dt, x0.data_ptr(), w.data_ptr(), y.data_ptr(), L.ptr(stats), n * h * wd, c0,
+                                           _stream()), "oct_rowdot_fwd")
+            else:
+                e._conv(src, wp, cout, taps, n, h, wd, y, stats=stats, **kd)
+
         if train_bn:
-            nblk = e._stat_blocks(cout, n, h, wd, src, taps, **kd)
+            nblk = lib.oct_rowdot_blocks(n * h * wd, c0) if rowdot else e._stat_blocks(cout, n, h, wd, src, taps, **kd)
             partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
-            e._conv(src, wp, cout, taps, n, h, wd, y, stats=partials, **kd)
+            conv(partials)
             mean, invstd = torch.empty_like(scale), torch.empty_like(scale)
             L.check(lib.oct_bn_finalize(partials.data_ptr(), nblk, cout, float(n * h * wd), gamma.data_ptr(),
                                         beta.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(),
@@ -168,7 +215,7 @@ class ConvAffineAct(torch.autograd.Function):
                                         scale.data_ptr(), shift.data_ptr(), L.ptr(cbias), _stream()), "oct_bn_finalize")
             bn.num_batches_tracked.add_(1)
         else:
-            e._conv(src, wp, cout, taps, n, h, wd, y, **kd)
+            conv()
             if bn is not None:
                 L.check(lib.oct_bn_eval_coeffs(cout, gamma.data_ptr(), beta.data_ptr(),
                                                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_EPS,
@@ -182,10 +229,14 @@ class ConvAffineAct(torch.autograd.Function):
                     shift.zero_()
         ctx.cfg = (dtype, bn, act, taps, train_bn, res is not None, cbias is not None, kk, lazy)
         ctx.xf = (xf0, xf1)
-        if lazy:
+        ctx.rowdot = rowdot
+        if lazy == "relu":
             ctx.save_for_backward(x0, x1, w, y, None, mean, invstd, scale, gamma, shift, alpha)
             ctx.mark_non_differentiable(scale, shift)
             return y, scale, shift
+        if lazy == "affine":
+            ctx.save_for_backward(x0, x1, w, y, None, mean, invstd, scale, gamma, shift, alpha)
+            return y
         out = e._act(n, h, wd, cout, dev)
         if res is not None:
             res = res.contiguous()
@@ -193,8 +244,10 @@ class ConvAffineAct(torch.autograd.Function):
             L.check(lib.oct_affine_prelu_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), alpha.data_ptr(),
                                              out.data_ptr(), n * h * wd, cout, _stream()), "oct_affine_prelu_fwd")
         else:
-            L.check(lib.oct_affine_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), act,
-                                           out.data_ptr(), n * h * wd, cout, _stream()), "oct_affine_act_fwd")
+            # res_shift: the residual is a raw tensor whose bias add was deferred (LazyAct, relu=False)
+            L.check(lib.oct_affine_res_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res),
+                                               L.ptr(res_shift), act, out.data_ptr(), n * h * wd, cout, _stream()),
+                    "oct_affine_res_act_fwd")
         ctx.save_for_backward(x0, x1, w, y, out, mean, invstd, scale, gamma, shift, alpha)
         return out
 
@@ -216,7 +269,7 @@ class ConvAffineAct(torch.autograd.Function):
         dout = dout.contiguous()
         if bn is not None and not train_bn:
             raise NotImplementedError("backward through an eval-mode BatchNorm is not on the HIP path")
-        if lazy:
+        if lazy == "relu":
             dz = dout       # dA: the mask [scale*y + shift > 0] is applied inside the two BN-backward passes
         elif act == L.ACT_PRELU:
             dz = torch.empty_like(dout)
@@ -237,7 +290,7 @@ class ConvAffineAct(torch.autograd.Function):
             # sums of dz and dz*xhat: the reduction kernel of the fused path with its ReLU mask held open
             nblk = lib.oct_dact_bn_reduce_blocks(n, h, wd, cout, 0)
             partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
-            if lazy:
+            if lazy == "relu":
                 msc, msh = scale, shift
             else:       # dz is already masked: hold the reduction kernel's ReLU mask open (0*y + 1 > 0)
                 msc, msh = e._const(0.0, cout, dev), e._const(1.0, cout, dev)
@@ -252,13 +305,14 @@ class ConvAffineAct(torch.autograd.Function):
             # dz stays intact when somebody else still reads it (the residual branch's gradient, autograd's own buffer)
             dy = torch.empty_like(dz) if (has_res or dz is dout) else dz
             L.check(lib.oct_bn_bwd_apply_to(e.dt, dy.data_ptr(), dz.data_ptr(), y.data_ptr(), coef.data_ptr(),
-                                            scale.data_ptr() if lazy else None, shift.data_ptr() if lazy else None,
+                                            scale.data_ptr() if lazy == "relu" else None,
+                                            shift.data_ptr() if lazy == "relu" else None,
                                             npix, cout, _stream()), "oct_bn_bwd_apply_to")
             if has_bias:
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
         else:
             dy = dz
-            if has_bias and cin % 32 == 0:
+            if has_bias and cin % 32 == 0 and not ctx.rowdot:
                 # bias gradient = sum over pixels of dY: one extra MFMA against a ones fragment inside the weight-gradient
                 # kernel instead of a separate pass over dY (the direct first-layer kernel has no such path: cin = 1, 3 ...)
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
@@ -267,7 +321,25 @@ class ConvAffineAct(torch.autograd.Function):
                 dcb = torch.empty(cout, dtype=torch.float32, device=dev)
                 L.check(lib.oct_channel_sum(e.dt, dy.data_ptr(), dcb.data_ptr(), npix, cout, 0, _stream()),
                         "oct_channel_sum")
-        src = Src(x0, c0, BNState(*xf0) if xf0 else None, x1, c1, BNState(*xf1) if xf1 else None)
+        if ctx.rowdot:
+            dw = torch.empty_like(w)
+            scratch = torch.empty((lib.oct_rowdot_blocks(npix, c0), c0), dtype=torch.float32, device=dev)
+            L.check(lib.oct_rowdot_bwd_weight(e.dt, dy.data_ptr(), x0.data_ptr(), dw.data_ptr(), scratch.data_ptr(), npix, c0, 0,
+                                              _stream()), "oct_rowdot_bwd_weight")
+            d0 = None
+            if ctx.needs_input_grad[3]:
+                d0 = e._act(n, h, wd, c0, dev)
+                L.check(lib.oct_rowdot_bwd_data(e.dt, dy.data_ptr(), w.data_ptr(), d0.data_ptr(), npix, c0, _stream()),
+                        "oct_rowdot_bwd_data")
+            return None, None, None, d0, None, dw, dcb, dgamma, dbeta, dres, dalpha, None, None, None, None
+        if DEBUG is not None:
+            DEBUG.append((f"{cout}x{cin}x{taps}@{h}x{wd} lazy={lazy} xf={bool(xf0)},{bool(xf1)} res={has_res}",
+                          dict(dout=dout.float().clone(), dy=dy.float().clone(), y=y.float().clone(), x0=x0.float().clone(),
+                               mean=None if mean is None else mean.clone(), invstd=None if invstd is None else invstd.clone(),
+                               scale=scale.clone(), shift=shift.clone(),
+                               dbeta=None if dbeta is None else dbeta.clone())))
+        src = Src(x0, c0, BNState(xf0[0], xf0[1], relu=xf0[2]) if xf0 else None,
+                  x1, c1, BNState(xf1[0], xf1[1], relu=xf1[2]) if xf1 else None)
         dwp = e._wgrad(src, dy, cout, taps, n, h, wd, dbias=dcb if fuse_bias else None, **kd)
         dw = torch.empty_like(w)
         if kk:
@@ -281,7 +353,7 @@ class ConvAffineAct(torch.autograd.Function):
             d0 = e._act(n, h, wd, c0, dev)
             d1 = e._act(n, h, wd, c1, dev) if c1 else None
             e._conv(Src(dy, cout), wp, cin, taps, n, h, wd, d0, y1=d1, split=c0 if c1 else 0, **kd)
-        return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres, dalpha, None, None, None
+        return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres, dalpha, None, None, None, None
 
 
 class MaxPool(torch.autograd.Function):
@@ -502,39 +574,55 @@ def conv_bn_act(dtype, x0, conv, bn=None, act=L.ACT_NONE, x1=None, res=None, pre
         if prelu.weight.numel() != 1:
             raise NotImplementedError("per-channel PReLU is not on the HIP path (the reference uses nn.PReLU())")
         act = L.ACT_PRELU
-    xf0 = xf1 = None
+    xf0 = xf1 = res_shift = None
     if isinstance(x0, LazyAct):
-        x0, xf0 = x0.y, (x0.scale, x0.shift)
+        x0, xf0 = x0.y, (x0.scale, x0.shift, x0.relu)
     if isinstance(x1, LazyAct):
-        x1, xf1 = x1.y, (x1.scale, x1.shift)
-    lazy = bool(lazy and bn is not None and bn.training and act == L.ACT_RELU and res is None
-                and tuple(conv.weight.shape[2:]) in ((1, 1), (3, 3)))
+        x1, xf1 = x1.y, (x1.scale, x1.shift, x1.relu)
+    if isinstance(res, LazyAct):
+        if res.relu:
+            raise NotImplementedError("a deferred BN + ReLU tensor cannot be a residual input: materialise() it")
+        res, res_shift = res.y, res.shift
+    kind = False
+    if lazy and LAZY[0] and tuple(conv.weight.shape[2:]) in ((1, 1), (3, 3)) and res is None and prelu is None:
+        if bn is not None and bn.training and act == L.ACT_RELU:
+            kind = "relu"
+        elif bn is None and act == L.ACT_NONE and LAZY[0] is True:
+            kind = "affine"
     r = ConvAffineAct.apply(dtype, bn, act, x0, x1, conv.weight, conv.bias,
                             bn.weight if bn is not None else None, bn.bias if bn is not None else None, res,
-                            prelu.weight if prelu is not None else None, xf0, xf1, lazy)
-    return LazyAct(*r) if lazy else r
+                            prelu.weight if prelu is not None else None, xf0, xf1, kind, res_shift)
+    if kind == "relu":
+        return LazyAct(*r)
+    if kind == "affine":
+        e = kernels(dtype)
+        cout = conv.weight.shape[0]
+        shift = conv.bias.detach() if conv.bias is not None else e._const(0.0, cout, r.device)
+        return LazyAct(r, e._const(1.0, cout, r.device), shift, relu=False)
+    return r
 
 
 def materialise(dtype, a):
     """LazyAct -> the activated NHWC tensor (for a consumer that is not a convolution); tensors pass through."""
     if not isinstance(a, LazyAct):
         return a
-    return _Materialise.apply(dtype, a.y, a.scale, a.shift)
+    return _Materialise.apply(dtype, a.y, a.scale, a.shift, a.relu)
 
 
 class _Materialise(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dtype, y, scale, shift):
+    def forward(ctx, dtype, y, scale, shift, relu):
         e = kernels(dtype)
         n, h, w, c = y.shape
         out = e._act(n, h, w, c, y.device)
-        L.check(L.lib().oct_affine_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, L.ACT_RELU,
-                                           out.data_ptr(), n * h * w, c, _stream()), "oct_affine_act_fwd")
+        L.check(L.lib().oct_affine_act_fwd(e.dt, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None,
+                                           L.ACT_RELU if relu else L.ACT_NONE, out.data_ptr(), n * h * w, c, _stream()),
+                "oct_affine_act_fwd")
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        return None, dout, None, None      # the producer's backward takes dA and masks it itself
+        return None, dout, None, None, None      # the producer's backward takes dA and masks it itself
 
 
 def to_nhwc(x, dtype):

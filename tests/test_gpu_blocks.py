@@ -134,3 +134,109 @@ def test_gate_product_backward_all_channel_paths(dt, tol, c):
     dx_ref, dp_ref = r.float() * p.float(), (r.float() * x.float()).sum(-1, keepdim=True)
     assert (x.grad.float() - dx_ref).abs().max() < tol
     assert ((p.grad.float() - dp_ref).abs().max() / dp_ref.abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype,c", [("f32", 32), ("bf16", 32), ("bf16", 64), ("f32", 8), ("bf16", 512)])
+def test_rowdot_kernels_match_numpy(dtype, c):
+    """oct_rowdot_{fwd,bwd_data,bwd_weight} (the one-output-channel 1x1 convolution of Attention_block.psi,
+    common.py:79-83) against numpy on a pixel count that is not a multiple of anything; integer-valued operands make
+    every product and sum exact, so the comparison is bit-for-bit."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(c)
+    npix = 3 * 37 * 53 + 1
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    dt = L.DT_F32 if dtype == "f32" else L.DT_BF16
+    x = rng.integers(-1, 2, (npix, c)).astype(np.float32)
+    w = (rng.integers(-1, 2, (c,)) * (rng.random(c) < 64.0 / c)).astype(np.float32)   # |y| <= 64-ish: exact in bf16
+    dy = rng.integers(-2, 3, (npix,)).astype(np.float32)
+    X, W, DY = torch.from_numpy(x).to("cuda", tdt), torch.from_numpy(w).cuda(), torch.from_numpy(dy).to("cuda", tdt)
+    assert lib.oct_rowdot_ok(c) == 1 and lib.oct_rowdot_ok(24) == 0 and lib.oct_rowdot_ok(1024) == 0
+    nblk = lib.oct_rowdot_blocks(npix, c)
+    Y = torch.empty(npix, dtype=tdt, device="cuda")
+    ST = torch.empty((nblk, 2, 1), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.oct_rowdot_fwd(dt, X.data_ptr(), W.data_ptr(), Y.data_ptr(), ST.data_ptr(), npix, c, st))
+    y = x @ w
+    assert np.abs(y).max() <= 256        # 8 significant bits: representable in bf16
+    assert np.array_equal(Y.float().cpu().numpy(), y)
+    s = ST.sum(0).cpu().numpy().ravel()
+    assert s[0] == y.sum() and s[1] == (y * y).sum()
+    DX = torch.empty_like(X)
+    L.check(lib.oct_rowdot_bwd_data(dt, DY.data_ptr(), W.data_ptr(), DX.data_ptr(), npix, c, st))
+    assert np.array_equal(DX.float().cpu().numpy(), dy[:, None] * w[None, :])
+    DW = torch.empty(c, dtype=torch.float32, device="cuda")
+    SC = torch.empty((nblk, c), dtype=torch.float32, device="cuda")
+    L.check(lib.oct_rowdot_bwd_weight(dt, DY.data_ptr(), X.data_ptr(), DW.data_ptr(), SC.data_ptr(), npix, c, 0, st))
+    assert np.array_equal(DW.cpu().numpy(), dy @ x)
+    L.check(lib.oct_rowdot_bwd_weight(dt, DY.data_ptr(), X.data_ptr(), DW.data_ptr(), SC.data_ptr(), npix, c, 1, st))
+    assert np.array_equal(DW.cpu().numpy(), 2 * (dy @ x))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_attention_gate_rowdot_path_matches_padded_gemm_path(dtype):
+    """Attention_block(F_g = F_l = 64, F_int = 32): psi on the streaming kernels vs the same module with the switch off
+    (psi as a 1 -> 32 padded GEMM on the MFMA kernels): output, input gradients, every parameter gradient, BN buffers."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    torch.manual_seed(3)
+    m = Dropins.Attention_block(F_g=64, F_l=64, F_int=32, compute_dtype=dtype).cuda().train()
+    g0, x0 = torch.randn(2, 64, 24, 40, device="cuda"), torch.randn(2, 64, 24, 40, device="cuda")
+    r = torch.randn(2, 64, 24, 40, device="cuda")
+    res = {}
+    e = ops.kernels(dtype)
+    init = {k: v.clone() for k, v in m.state_dict().items()}
+    for off in (False, True):
+        m.load_state_dict(init)
+        m.zero_grad(set_to_none=True)
+        e.rowdot_off = off
+        try:
+            g, x = g0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+            out = m(g, x)
+            (out * r).sum().backward()
+        finally:
+            e.rowdot_off = False
+        res[off] = dict(out=out.detach(), gg=g.grad, gx=x.grad, **{k: p.grad for k, p in m.named_parameters()},
+                        **{"b/" + k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    rel = 2e-4 if dtype == "f32" else 2e-2     # fp32: the two paths only differ in summation order
+    for k in res[False]:
+        a, b = res[False][k].float(), res[True][k].float()
+        tol = rel * max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cls,kw,shape", [("AttU_Net", dict(channels=[8, 16, 32, 64, 128]), (2, 1, 32, 48)),
+                                          ("U_Net", {}, (1, 1, 32, 32))])
+def test_deferred_activation_schedule_is_bit_identical_to_the_materialised_one(dtype, cls, kw, shape):
+    """ops.LazyAct (BN + ReLU and bias adds applied by the consuming convolution, never written) against the same
+    network with every activation materialised (ops.LAZY[0] = False): logits, input gradient and -- with the ordered
+    weight-gradient reduction -- every parameter gradient are EQUAL, in fp32 and in bf16."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment.SD_Layer_Net import unet as U
+    torch.manual_seed(11)
+    m = getattr(U, cls)(shape[1], 3, compute_dtype=dtype, **kw).cuda().train()
+    x0 = torch.randn(*shape, device="cuda")
+    t = torch.randint(0, 3, (shape[0], shape[2], shape[3]), device="cuda")
+    init = {k: v.clone() for k, v in m.state_dict().items()}
+    e = ops.kernels(dtype)
+    res = {}
+    keep_det, keep_lazy = e.deterministic, ops.LAZY[0]
+    try:
+        e.deterministic = True
+        for setting in (True, False):
+            ops.LAZY[0] = setting
+            m.load_state_dict(init)
+            m.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            out = m(x)
+            F.cross_entropy(out, t).backward()
+            res[setting] = dict(out=out.detach().clone(), gx=x.grad.clone(), **{k: p.grad.clone() for k, p in m.named_parameters()},
+                                **{"b/" + k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    finally:
+        e.deterministic, ops.LAZY[0] = keep_det, keep_lazy
+    # (two bias gradients go through oct_channel_sum's atomics -- convolutions without BN whose Cin is not a multiple of
+    # 32 -- and are equal up to summation order)
+    loose = ("Conv_1x1.bias", "Conv1.init_conv.bias")
+    bad = [k for k in res[True] if not (torch.allclose(res[True][k], res[False][k], rtol=1e-4, atol=1e-7)
+                                        if k in loose else torch.equal(res[True][k], res[False][k]))]
+    assert bad == [], bad
