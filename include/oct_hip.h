@@ -251,18 +251,19 @@ int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const
 int oct_bn_bwd_apply_to(int dtype, void* dst, const void* g, const void* y, const float* coef, const float* scale,
                         const float* shift, size_t npix, int c, void* stream);
 /* ------------------------------------------------------------------------------------------
- * 1x1 convolution with ONE output channel: Attention_block's psi = Conv2d(F_int, 1, 1) (SD_Layer_Net/common.py:79-83).
- * Three streaming kernels instead of GEMMs padded 1 -> 32 (c = 8 * 2^k <= 512: oct_rowdot_ok; other widths stay on
- * oct_conv_forward / oct_conv_wgrad).  x, dx: [npix][c] NHWC; y, dy: [npix]; w, dw: [c] fp32 (torch (1,c,1,1)).
- *   fwd       : y = x . w; stats (may be NULL): [oct_rowdot_blocks][2][1] partial sum / sum of squares (oct_bn_finalize rows)
- *   bwd_data  : dx[pix][c] = dy[pix] * w[c]
- *   bwd_weight: dw[c] (+)= sum_pix dy[pix] * x[pix][c]; partials: scratch [oct_rowdot_blocks][c], summed in block order
+ * 1x1 convolution with k <= 4 output channels: Attention_block's psi = Conv2d(F_int, 1, 1) (SD_Layer_Net/common.py:79-83)
+ * and the heads Conv_1x1 = Conv2d(64, output_ch, 1) (SD_Layer_Net/unet.py:38,113).  Three streaming kernels instead of
+ * GEMMs padded k -> 32 (c = 8 * 2^j <= 512, k <= 4: oct_rowdot_ok; other shapes stay on oct_conv_forward / oct_conv_wgrad).
+ * x, dx: [npix][c] NHWC; y, dy: [npix][k]; w, dw: [k][c] fp32 (torch (k,c,1,1)).
+ *   fwd       : y = x . w^T; stats (may be NULL): [oct_rowdot_blocks][2][k] partial sum / sum of squares (oct_bn_finalize rows)
+ *   bwd_data  : dx[pix][c] = sum_k dy[pix][k] * w[k][c]
+ *   bwd_weight: dw[k][c] (+)= sum_pix dy[pix][k] * x[pix][c]; partials: scratch [oct_rowdot_blocks][k*c], summed in a fixed order
  * ------------------------------------------------------------------------------------------ */
-int oct_rowdot_ok(int c);
+int oct_rowdot_ok(int c, int k);
 int oct_rowdot_blocks(size_t npix, int c);
-int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y, float* stats, size_t npix, int c, void* stream);
-int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, void* dx, size_t npix, int c, void* stream);
-int oct_rowdot_bwd_weight(int dtype, const void* dy, const void* x, float* dw, float* partials, size_t npix, int c,
+int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y, float* stats, size_t npix, int c, int k, void* stream);
+int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, void* dx, size_t npix, int c, int k, void* stream);
+int oct_rowdot_bwd_weight(int dtype, const void* dy, const void* x, float* dw, float* partials, size_t npix, int c, int k,
                           int accumulate, void* stream);
 
 /* per-channel sum over pixels of an NHWC tensor (bias gradient of ConvTranspose2d) */

@@ -114,11 +114,11 @@ SIGNATURES = {
     "oct_bn_bwd_apply_to": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                     c_void_p]),
     "oct_channel_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
-    "oct_rowdot_ok": (c_int, [c_int]),
+    "oct_rowdot_ok": (c_int, [c_int, c_int]),
     "oct_rowdot_blocks": (c_int, [c_size_t, c_int]),
-    "oct_rowdot_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
-    "oct_rowdot_bwd_data": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
-    "oct_rowdot_bwd_weight": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "oct_rowdot_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "oct_rowdot_bwd_data": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "oct_rowdot_bwd_weight": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "oct_head_blocks": (c_int, [C.POINTER(HeadDesc)]),
     "oct_head_forward": (c_int, [C.POINTER(HeadDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

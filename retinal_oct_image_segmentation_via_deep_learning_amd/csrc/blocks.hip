@@ -635,15 +635,20 @@ extern "C" int oct_depth_pool_bwd(int dtype, const void* p2, const void* dout, v
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1x1 convolution with ONE output channel -- Attention_block's psi (common.py:79-83: Conv2d(F_int, 1, 1)):
-//   y[pix] = sum_c x[pix][c] * w[c],  dx[pix][c] = dy[pix] * w[c],  dw[c] = sum_pix dy[pix] * x[pix][c].
-// On the MFMA kernels that is a GEMM with 31 of 32 output rows (or K lanes) padded: 3.8 ms per cfg4 step for what is
-// three streaming passes over the F_int-channel tensor (0.7 GB each).  G = c/8 lanes share a pixel (16-B loads /
-// stores), the dot product closes with log2(G) shuffles.  bf16 mode rounds the weight to bf16 first, like the packed
-// MFMA operand it replaces; sums are fp32.
+// 1x1 convolution with K <= 4 output channels -- Attention_block's psi (common.py:79-83: Conv2d(F_int, 1, 1)) and the
+// SD_Layer_Net heads Conv_1x1 (unet.py:38,113: Conv2d(64, output_ch, 1)):
+//   y[pix][k] = sum_c x[pix][c] * w[k][c],  dx[pix][c] = sum_k dy[pix][k] * w[k][c],  dw[k][c] = sum_pix dy[pix][k] * x[pix][c].
+// On the MFMA kernels that is a GEMM with 28-31 of 32 output rows (or K lanes) padded: 3.8 + 1.9 ms per cfg4 step for what
+// are three streaming passes over the input tensor each.  G = c/8 lanes share a pixel (16-B loads / stores), a dot
+// product closes with log2(G) shuffles.  bf16 mode rounds the weight to bf16 first, like the packed MFMA operand it
+// replaces; sums are fp32.
 // ---------------------------------------------------------------------------------------------
 #define RD_MAX_BLOCKS 512
-static inline bool rowdot_shape_ok(int c) { const int g = c / 8; return c % 8 == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0; }
+#define RD_MAX_K 4
+static inline bool rowdot_shape_ok(int c, int k) {
+  const int g = c / 8;
+  return c % 8 == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 && k >= 1 && k <= RD_MAX_K;
+}
 static inline int rowdot_grid(size_t npix, int c) {
   const size_t ppb = BK_THREADS / (c / 8);
   size_t b = (npix + 4 * ppb - 1) / (4 * ppb);
@@ -651,23 +656,33 @@ static inline int rowdot_grid(size_t npix, int c) {
   if (b < 1) b = 1;
   return (int)b;
 }
-extern "C" int oct_rowdot_ok(int c) { return rowdot_shape_ok(c) ? 1 : 0; }
-extern "C" int oct_rowdot_blocks(size_t npix, int c) { return rowdot_shape_ok(c) ? rowdot_grid(npix, c) : 0; }
+extern "C" int oct_rowdot_ok(int c, int k) { return rowdot_shape_ok(c, k) ? 1 : 0; }
+extern "C" int oct_rowdot_blocks(size_t npix, int c) { return rowdot_shape_ok(c, 1) ? rowdot_grid(npix, c) : 0; }
 
 template <typename T> __device__ __forceinline__ float rd_round(float v) { return to_f32(from_f32<T>(v)); }
 
-template <typename T>
+template <typename T, int K>
 __global__ void __launch_bounds__(BK_THREADS) rowdot_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
                                                                 float* __restrict__ stats, size_t npix, int c) {
   const int G = c / 8, gi = threadIdx.x % G, slot = threadIdx.x / G, ppb = BK_THREADS / G;
-  float wv[8];
+  float wv[K][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) wv[j] = rd_round<T>(w[gi * 8 + j]);
-  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[k][j] = rd_round<T>(w[(size_t)k * c + gi * 8 + j]);
+  float s1[K], s2[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
   const size_t stride = (size_t)gridDim.x * ppb;
-  auto finish = [&](float d, size_t pix) {
-    for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
-    if (gi == 0) { y[pix] = from_f32<T>(d); s1 += d; s2 = fmaf(d, d, s2); }
+  auto one = [&](const float (&xv)[8], size_t pix) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d = fmaf(xv[j], wv[k][j], d);
+      for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
+      if (gi == 0) { y[pix * K + k] = from_f32<T>(d); s1[k] += d; s2[k] = fmaf(d, d, s2[k]); }
+    }
   };
   size_t pix = (size_t)blockIdx.x * ppb + slot;
   for (; pix + 3 * stride < npix; pix += 4 * stride) {   // four pixels in flight per lane
@@ -675,86 +690,105 @@ __global__ void __launch_bounds__(BK_THREADS) rowdot_fwd_kernel(const T* __restr
 #pragma unroll
     for (int u = 0; u < 4; ++u) load_vec_nt<T, 8>(x + (pix + u * stride) * c + gi * 8, xv[u]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float d = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) d = fmaf(xv[u][j], wv[j], d);
-      finish(d, pix + u * stride);
-    }
+    for (int u = 0; u < 4; ++u) one(xv[u], pix + u * stride);
   }
   for (; pix < npix; pix += stride) {
     float xv[8];
     load_vec<T, 8>(x + pix * c + gi * 8, xv);
-    float d = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) d = fmaf(xv[j], wv[j], d);
-    finish(d, pix);
+    one(xv, pix);
   }
-  if (stats) {   // one row [2][1] per workgroup, the layout oct_bn_finalize reads
-    __shared__ float red[2][BK_THREADS / 64];
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  if (stats) {   // one row [2][K] per workgroup, the layout oct_bn_finalize reads
+    __shared__ float red[2][K][BK_THREADS / 64];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float a = s1[k], b = s2[k];
+      for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if ((threadIdx.x & 63) == 0) { red[0][k][threadIdx.x >> 6] = a; red[1][k][threadIdx.x >> 6] = b; }
+    }
     __syncthreads();
-    if (threadIdx.x < 2) stats[(size_t)blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (threadIdx.x < 2 * K) {
+      const int st = threadIdx.x / K, k = threadIdx.x % K;
+      stats[((size_t)blockIdx.x * 2 + st) * K + k] = red[st][k][0] + red[st][k][1] + red[st][k][2] + red[st][k][3];
+    }
   }
 }
 
-template <typename T>
+template <typename T, int K>
 __global__ void __launch_bounds__(BK_THREADS) rowdot_bwd_data_kernel(const T* __restrict__ dy, const float* __restrict__ w,
                                                                      T* __restrict__ dx, size_t npix, int c) {
   const int G = c / 8, gi = threadIdx.x % G, slot = threadIdx.x / G, ppb = BK_THREADS / G;
-  float wv[8];
+  float wv[K][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) wv[j] = rd_round<T>(w[gi * 8 + j]);
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[k][j] = rd_round<T>(w[(size_t)k * c + gi * 8 + j]);
   const size_t stride = (size_t)gridDim.x * ppb;
   for (size_t pix = (size_t)blockIdx.x * ppb + slot; pix < npix; pix += stride) {
-    const float g = to_f32(dy[pix]);
     float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = g * wv[j];
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float g = to_f32(dy[pix * K + k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaf(g, wv[k][j], o[j]);
+    }
     store_vec_nt<T, 8>(dx + pix * c + gi * 8, o);
   }
 }
 
-// per-workgroup partial rows part[block][c] (plain stores), summed in block order by rowdot_bwd_weight_sum_kernel:
-// the weight gradient is bit-reproducible from run to run
-template <typename T>
+// per-workgroup partial rows part[block][K*c] (plain stores), summed in a fixed order by rowdot_bwd_weight_sum_kernel:
+// the weight gradient is bit-reproducible from run to run.  bias (may be NULL): part_b[block][K] = sum_pix dy[pix][k].
+template <typename T, int K>
 __global__ void __launch_bounds__(BK_THREADS) rowdot_bwd_weight_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                        float* __restrict__ part, size_t npix, int c) {
   const int G = c / 8, gi = threadIdx.x % G, slot = threadIdx.x / G, ppb = BK_THREADS / G;
-  float acc[8];
+  float acc[K][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
   const size_t stride = (size_t)gridDim.x * ppb;
   size_t pix = (size_t)blockIdx.x * ppb + slot;
   for (; pix + 3 * stride < npix; pix += 4 * stride) {
-    float xv[4][8], g[4];
+    float xv[4][8], g[4][K];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { load_vec_nt<T, 8>(x + (pix + u * stride) * c + gi * 8, xv[u]); g[u] = to_f32(dy[pix + u * stride]); }
+    for (int u = 0; u < 4; ++u) {
+      load_vec_nt<T, 8>(x + (pix + u * stride) * c + gi * 8, xv[u]);
+#pragma unroll
+      for (int k = 0; k < K; ++k) g[u][k] = to_f32(dy[(pix + u * stride) * K + k]);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(g[u], xv[u][j], acc[j]);
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(g[u][k], xv[u][j], acc[k][j]);
   }
   for (; pix < npix; pix += stride) {
     float xv[8];
     load_vec<T, 8>(x + pix * c + gi * 8, xv);
-    const float g = to_f32(dy[pix]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, xv[j], acc[j]);
+    for (int k = 0; k < K; ++k) {
+      const float g = to_f32(dy[pix * K + k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(g, xv[j], acc[k][j]);
+    }
   }
   // lanes gi, gi + G, gi + 2G ... of a wave own the same channels: fold them, then the four waves through LDS
-  __shared__ float red[BK_THREADS / 64][512];
+  __shared__ float red[BK_THREADS / 64][K * 512];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float v = acc[j];
-    for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) < G) red[threadIdx.x >> 6][gi * 8 + j] = v;
-  }
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[k][j];
+      for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      if ((threadIdx.x & 63) < G) red[threadIdx.x >> 6][k * c + gi * 8 + j] = v;
+    }
   __syncthreads();
-  for (int i = threadIdx.x; i < c; i += BK_THREADS) part[(size_t)blockIdx.x * c + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  for (int i = threadIdx.x; i < K * c; i += BK_THREADS) part[(size_t)blockIdx.x * (K * c) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
-// 16 channels x 16 row-slices per workgroup; slice s adds rows s, s + 16, ... in order, the slices are folded in order:
+// 16 columns x 16 row-slices per workgroup; slice s adds rows s, s + 16, ... in order, the slices are folded in order:
 // a fixed summation tree (reproducible), 32 dependent loads per thread instead of 512
 __global__ void __launch_bounds__(256) rowdot_bwd_weight_sum_kernel(const float* __restrict__ part, int nblk, int c,
                                                                     float* __restrict__ dw, int accumulate) {
@@ -773,35 +807,44 @@ __global__ void __launch_bounds__(256) rowdot_bwd_weight_sum_kernel(const float*
   }
 }
 
-extern "C" int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y, float* stats, size_t npix, int c, void* stream) {
+#define RD_LAUNCH(KERNEL, T, ...)                                                                                  \
+  do {                                                                                                             \
+    if (k == 1) hipLaunchKernelGGL((KERNEL<T, 1>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);               \
+    else if (k == 2) hipLaunchKernelGGL((KERNEL<T, 2>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
+    else if (k == 3) hipLaunchKernelGGL((KERNEL<T, 3>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
+    else hipLaunchKernelGGL((KERNEL<T, 4>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);                      \
+  } while (0)
+
+extern "C" int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y, float* stats, size_t npix, int c, int k, void* stream) {
   OCT_CHECK(x && w && y && npix > 0, "oct_rowdot_fwd: bad args");
-  OCT_CHECK(rowdot_shape_ok(c), "oct_rowdot_fwd: c = %d must be 8 * 2^k, at most 512 (ask oct_rowdot_ok)", c);
+  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_fwd: c = %d must be 8 * 2^j <= 512 and k = %d in 1..4 (ask oct_rowdot_ok)", c, k);
   const int grid = rowdot_grid(npix, c);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OCT_DT_BF16) hipLaunchKernelGGL(rowdot_fwd_kernel<bf16_t>, dim3(grid), dim3(BK_THREADS), 0, s, (const bf16_t*)x, w, (bf16_t*)y, stats, npix, c);
-  else if (dtype == OCT_DT_F32) hipLaunchKernelGGL(rowdot_fwd_kernel<float>, dim3(grid), dim3(BK_THREADS), 0, s, (const float*)x, w, (float*)y, stats, npix, c);
+  if (dtype == OCT_DT_BF16) RD_LAUNCH(rowdot_fwd_kernel, bf16_t, (const bf16_t*)x, w, (bf16_t*)y, stats, npix, c);
+  else if (dtype == OCT_DT_F32) RD_LAUNCH(rowdot_fwd_kernel, float, (const float*)x, w, (float*)y, stats, npix, c);
   else OCT_CHECK(false, "oct_rowdot_fwd: bad dtype");
   return oct_check_launch("rowdot_fwd");
 }
-extern "C" int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, void* dx, size_t npix, int c, void* stream) {
+extern "C" int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, void* dx, size_t npix, int c, int k, void* stream) {
   OCT_CHECK(dy && w && dx && npix > 0, "oct_rowdot_bwd_data: bad args");
-  OCT_CHECK(rowdot_shape_ok(c), "oct_rowdot_bwd_data: c = %d must be 8 * 2^k, at most 512", c);
+  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_bwd_data: c = %d must be 8 * 2^j <= 512 and k = %d in 1..4", c, k);
   const int grid = rowdot_grid(npix, c);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OCT_DT_BF16) hipLaunchKernelGGL(rowdot_bwd_data_kernel<bf16_t>, dim3(grid), dim3(BK_THREADS), 0, s, (const bf16_t*)dy, w, (bf16_t*)dx, npix, c);
-  else if (dtype == OCT_DT_F32) hipLaunchKernelGGL(rowdot_bwd_data_kernel<float>, dim3(grid), dim3(BK_THREADS), 0, s, (const float*)dy, w, (float*)dx, npix, c);
+  if (dtype == OCT_DT_BF16) RD_LAUNCH(rowdot_bwd_data_kernel, bf16_t, (const bf16_t*)dy, w, (bf16_t*)dx, npix, c);
+  else if (dtype == OCT_DT_F32) RD_LAUNCH(rowdot_bwd_data_kernel, float, (const float*)dy, w, (float*)dx, npix, c);
   else OCT_CHECK(false, "oct_rowdot_bwd_data: bad dtype");
   return oct_check_launch("rowdot_bwd_data");
 }
 extern "C" int oct_rowdot_bwd_weight(int dtype, const void* dy, const void* x, float* dw, float* partials, size_t npix, int c,
-                                     int accumulate, void* stream) {
+                                     int k, int accumulate, void* stream) {
   OCT_CHECK(dy && x && dw && partials && npix > 0, "oct_rowdot_bwd_weight: bad args");
-  OCT_CHECK(rowdot_shape_ok(c), "oct_rowdot_bwd_weight: c = %d must be 8 * 2^k, at most 512", c);
+  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_bwd_weight: c = %d must be 8 * 2^j <= 512 and k = %d in 1..4", c, k);
   const int grid = rowdot_grid(npix, c);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OCT_DT_BF16) hipLaunchKernelGGL(rowdot_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(BK_THREADS), 0, s, (const bf16_t*)dy, (const bf16_t*)x, partials, npix, c);
-  else if (dtype == OCT_DT_F32) hipLaunchKernelGGL(rowdot_bwd_weight_kernel<float>, dim3(grid), dim3(BK_THREADS), 0, s, (const float*)dy, (const float*)x, partials, npix, c);
+  if (dtype == OCT_DT_BF16) RD_LAUNCH(rowdot_bwd_weight_kernel, bf16_t, (const bf16_t*)dy, (const bf16_t*)x, partials, npix, c);
+  else if (dtype == OCT_DT_F32) RD_LAUNCH(rowdot_bwd_weight_kernel, float, (const float*)dy, (const float*)x, partials, npix, c);
   else OCT_CHECK(false, "oct_rowdot_bwd_weight: bad dtype");
-  hipLaunchKernelGGL(rowdot_bwd_weight_sum_kernel, dim3((c + 15) / 16), dim3(256), 0, s, partials, grid, c, dw, accumulate);
+  hipLaunchKernelGGL(rowdot_bwd_weight_sum_kernel, dim3((k * c + 15) / 16), dim3(256), 0, s, partials, grid, k * c, dw, accumulate);
   return oct_check_launch("rowdot_bwd_weight");
 }
+#undef RD_LAUNCH

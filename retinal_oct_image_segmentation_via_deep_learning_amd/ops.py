@@ -187,9 +187,8 @@ class ConvAffineAct(torch.autograd.Function):
             raise RuntimeError("a lazy BN + ReLU output needs a train-mode BatchNorm + ReLU without residual")
         if lazy == "affine" and not (bn is None and act == L.ACT_NONE and res is None):
             raise RuntimeError("a lazy affine output is a bare convolution (+ bias)")
-        # one output channel (Attention_block's psi): three streaming kernels instead of GEMMs padded 1 -> 32
-        rowdot = (taps == 1 and cout == 1 and x1 is None and xf0 is None and lib.oct_rowdot_ok(c0) == 1
-                  and not e.rowdot_off)
+        # 1-4 output channels (Attention_block's psi, the heads): three streaming kernels instead of GEMMs padded to 32 rows
+        rowdot = (taps == 1 and x1 is None and xf0 is None and lib.oct_rowdot_ok(c0, cout) == 1 and not e.rowdot_off)
         wp = None if rowdot else packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
         y = e._act(n, h, wd, cout, dev)
         scale = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -199,7 +198,7 @@ class ConvAffineAct(torch.autograd.Function):
 
         def conv(stats=None):
             if rowdot:
-                L.check(lib.oct_rowdot_fwd(e.dt, x0.data_ptr(), w.data_ptr(), y.data_ptr(), L.ptr(stats), n * h * wd, c0,
+                L.check(lib.oct_rowdot_fwd(e.dt, x0.data_ptr(), w.data_ptr(), y.data_ptr(), L.ptr(stats), n * h * wd, c0, cout,
                                            _stream()), "oct_rowdot_fwd")
             else:
                 e._conv(src, wp, cout, taps, n, h, wd, y, stats=stats, **kd)
@@ -323,13 +322,13 @@ class ConvAffineAct(torch.autograd.Function):
                         "oct_channel_sum")
         if ctx.rowdot:
             dw = torch.empty_like(w)
-            scratch = torch.empty((lib.oct_rowdot_blocks(npix, c0), c0), dtype=torch.float32, device=dev)
-            L.check(lib.oct_rowdot_bwd_weight(e.dt, dy.data_ptr(), x0.data_ptr(), dw.data_ptr(), scratch.data_ptr(), npix, c0, 0,
-                                              _stream()), "oct_rowdot_bwd_weight")
+            scratch = torch.empty((lib.oct_rowdot_blocks(npix, c0), cout * c0), dtype=torch.float32, device=dev)
+            L.check(lib.oct_rowdot_bwd_weight(e.dt, dy.data_ptr(), x0.data_ptr(), dw.data_ptr(), scratch.data_ptr(), npix, c0,
+                                              cout, 0, _stream()), "oct_rowdot_bwd_weight")
             d0 = None
             if ctx.needs_input_grad[3]:
                 d0 = e._act(n, h, wd, c0, dev)
-                L.check(lib.oct_rowdot_bwd_data(e.dt, dy.data_ptr(), w.data_ptr(), d0.data_ptr(), npix, c0, _stream()),
+                L.check(lib.oct_rowdot_bwd_data(e.dt, dy.data_ptr(), w.data_ptr(), d0.data_ptr(), npix, c0, cout, _stream()),
                         "oct_rowdot_bwd_data")
             return None, None, None, d0, None, dw, dcb, dgamma, dbeta, dres, dalpha, None, None, None, None
         if DEBUG is not None:

@@ -136,41 +136,42 @@ def test_gate_product_backward_all_channel_paths(dt, tol, c):
     assert ((p.grad.float() - dp_ref).abs().max() / dp_ref.abs().max()) < tol
 
 
-@pytest.mark.parametrize("dtype,c", [("f32", 32), ("bf16", 32), ("bf16", 64), ("f32", 8), ("bf16", 512)])
-def test_rowdot_kernels_match_numpy(dtype, c):
-    """oct_rowdot_{fwd,bwd_data,bwd_weight} (the one-output-channel 1x1 convolution of Attention_block.psi,
-    common.py:79-83) against numpy on a pixel count that is not a multiple of anything; integer-valued operands make
-    every product and sum exact, so the comparison is bit-for-bit."""
+@pytest.mark.parametrize("dtype,c,k", [("f32", 32, 1), ("bf16", 32, 1), ("bf16", 64, 3), ("f32", 8, 4), ("bf16", 512, 1), ("f32", 64, 2),
+                                       ("bf16", 512, 4)])
+def test_rowdot_kernels_match_numpy(dtype, c, k):
+    """oct_rowdot_{fwd,bwd_data,bwd_weight} (1x1 convolutions with 1-4 output channels: Attention_block.psi,
+    common.py:79-83, and the heads Conv_1x1, unet.py:38,113) against numpy on a pixel count that is not a multiple of
+    anything; integer-valued operands make every product and sum exact, so the comparison is bit-for-bit."""
     from retinal_oct_image_segmentation_via_deep_learning_amd import _lib as L
     lib = L.lib()
-    rng = np.random.default_rng(c)
+    rng = np.random.default_rng(c + k)
     npix = 3 * 37 * 53 + 1
     tdt = torch.float32 if dtype == "f32" else torch.bfloat16
     dt = L.DT_F32 if dtype == "f32" else L.DT_BF16
     x = rng.integers(-1, 2, (npix, c)).astype(np.float32)
-    w = (rng.integers(-1, 2, (c,)) * (rng.random(c) < 64.0 / c)).astype(np.float32)   # |y| <= 64-ish: exact in bf16
-    dy = rng.integers(-2, 3, (npix,)).astype(np.float32)
+    w = (rng.integers(-1, 2, (k, c)) * (rng.random((k, c)) < 64.0 / c)).astype(np.float32)   # |y| <= 64-ish: exact in bf16
+    dy = rng.integers(-2, 3, (npix, k)).astype(np.float32)
     X, W, DY = torch.from_numpy(x).to("cuda", tdt), torch.from_numpy(w).cuda(), torch.from_numpy(dy).to("cuda", tdt)
-    assert lib.oct_rowdot_ok(c) == 1 and lib.oct_rowdot_ok(24) == 0 and lib.oct_rowdot_ok(1024) == 0
+    assert lib.oct_rowdot_ok(c, k) == 1 and lib.oct_rowdot_ok(24, 1) == 0 and lib.oct_rowdot_ok(1024, 1) == 0 and lib.oct_rowdot_ok(64, 5) == 0
     nblk = lib.oct_rowdot_blocks(npix, c)
-    Y = torch.empty(npix, dtype=tdt, device="cuda")
-    ST = torch.empty((nblk, 2, 1), dtype=torch.float32, device="cuda")
+    Y = torch.empty((npix, k), dtype=tdt, device="cuda")
+    ST = torch.empty((nblk, 2, k), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    L.check(lib.oct_rowdot_fwd(dt, X.data_ptr(), W.data_ptr(), Y.data_ptr(), ST.data_ptr(), npix, c, st))
-    y = x @ w
+    L.check(lib.oct_rowdot_fwd(dt, X.data_ptr(), W.data_ptr(), Y.data_ptr(), ST.data_ptr(), npix, c, k, st))
+    y = x @ w.T
     assert np.abs(y).max() <= 256        # 8 significant bits: representable in bf16
     assert np.array_equal(Y.float().cpu().numpy(), y)
-    s = ST.sum(0).cpu().numpy().ravel()
-    assert s[0] == y.sum() and s[1] == (y * y).sum()
+    s = ST.sum(0).cpu().numpy()
+    assert np.array_equal(s[0], y.sum(0)) and np.array_equal(s[1], (y * y).sum(0))
     DX = torch.empty_like(X)
-    L.check(lib.oct_rowdot_bwd_data(dt, DY.data_ptr(), W.data_ptr(), DX.data_ptr(), npix, c, st))
-    assert np.array_equal(DX.float().cpu().numpy(), dy[:, None] * w[None, :])
-    DW = torch.empty(c, dtype=torch.float32, device="cuda")
-    SC = torch.empty((nblk, c), dtype=torch.float32, device="cuda")
-    L.check(lib.oct_rowdot_bwd_weight(dt, DY.data_ptr(), X.data_ptr(), DW.data_ptr(), SC.data_ptr(), npix, c, 0, st))
-    assert np.array_equal(DW.cpu().numpy(), dy @ x)
-    L.check(lib.oct_rowdot_bwd_weight(dt, DY.data_ptr(), X.data_ptr(), DW.data_ptr(), SC.data_ptr(), npix, c, 1, st))
-    assert np.array_equal(DW.cpu().numpy(), 2 * (dy @ x))
+    L.check(lib.oct_rowdot_bwd_data(dt, DY.data_ptr(), W.data_ptr(), DX.data_ptr(), npix, c, k, st))
+    assert np.array_equal(DX.float().cpu().numpy(), dy @ w)
+    DW = torch.empty((k, c), dtype=torch.float32, device="cuda")
+    SC = torch.empty((nblk, k * c), dtype=torch.float32, device="cuda")
+    L.check(lib.oct_rowdot_bwd_weight(dt, DY.data_ptr(), X.data_ptr(), DW.data_ptr(), SC.data_ptr(), npix, c, k, 0, st))
+    assert np.array_equal(DW.cpu().numpy(), dy.T @ x)
+    L.check(lib.oct_rowdot_bwd_weight(dt, DY.data_ptr(), X.data_ptr(), DW.data_ptr(), SC.data_ptr(), npix, c, k, 1, st))
+    assert np.array_equal(DW.cpu().numpy(), 2 * (dy.T @ x))
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -205,7 +206,7 @@ def test_attention_gate_rowdot_path_matches_padded_gemm_path(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("cls,kw,shape", [("AttU_Net", dict(channels=[8, 16, 32, 64, 128]), (2, 1, 32, 48)),
+@pytest.mark.parametrize("cls,kw,shape", [("AttU_Net", dict(channels=[16, 32, 64, 128, 256]), (2, 1, 32, 48)),
                                           ("U_Net", {}, (1, 1, 32, 32))])
 def test_deferred_activation_schedule_is_bit_identical_to_the_materialised_one(dtype, cls, kw, shape):
     """ops.LazyAct (BN + ReLU and bias adds applied by the consuming convolution, never written) against the same
