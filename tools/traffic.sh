@@ -6,6 +6,6 @@ TAG=$1
 O=$GRAFT_REPO_ROOT/gpurun_out
 STEPS=2; WARM=1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/traffic_$TAG/fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > $O/traffic_$TAG.fetch.log 2>&1 &&
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/traffic_$TAG/write -- python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > $O/traffic_$TAG.write.log 2>&1 &&
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/traffic_$TAG/fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-h2d > $O/traffic_$TAG.fetch.log 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/traffic_$TAG/write -- python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-h2d > $O/traffic_$TAG.write.log 2>&1 &&
 cd $GRAFT_REPO_ROOT && python3 tools/traffic_report.py $O/traffic_$TAG $((STEPS + WARM + 1)) > $O/traffic_$TAG.json && cat $O/traffic_$TAG.json
