@@ -59,6 +59,28 @@ def train_flops(features, classes, h, w, in_ch=1):
     return 3.0 * fwd - first
 
 
+def bionet_train_flops(classes, h, w, in_ch=1):
+    """Algorithmic conv FLOPs of one B-scan's training step of BioNet_2020.UNet (three poolings, widths 64-512,
+    BioNet_2020.py:24-75): 3 x forward minus the data gradient of the first convolution, as train_flops()."""
+    first = 2.0 * h * w * 9 * in_ch * 64
+    fwd, hh, ww, cin = 0.0, h, w, in_ch
+    for c in (64, 128, 256, 512):
+        fwd += 2.0 * hh * ww * 9 * (cin * c + c * c)
+        cin = c
+        if c != 512:
+            hh //= 2
+            ww //= 2
+    c = 512
+    for _ in range(3):
+        fwd += 2.0 * hh * ww * c * (c // 2) * 4          # ConvTranspose2d k2 s2
+        hh *= 2
+        ww *= 2
+        c //= 2
+        fwd += 2.0 * hh * ww * 9 * (2 * c * c + c * c)
+    fwd += 2.0 * hh * ww * 64 * classes
+    return 3.0 * fwd - first
+
+
 def csrc_digest():
     """sha256 over the kernel sources: profiles/*_traffic.json records it, so a traffic figure measured on
     other kernels than the ones being timed is recognised as stale."""
@@ -86,10 +108,11 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercise the multi-rank plumbing on CPU tensors")
     ap.add_argument("--bucket-mb", type=float, default=3.0, help="gradient bucket threshold (MB)")
-    ap.add_argument("--config", default="cfg2", choices=("cfg2", "cfg4", "cfg5"),
+    ap.add_argument("--config", default="cfg2", choices=("cfg2", "cfg1", "cfg4", "cfg5"),
                     help="cfg2 (default, the headline line the driver runs): Layers_Segment UNet(1,8) 512x1024 batch 32; "
+                         "cfg1: BioNet_2020.UNet(1,2) 256x256 batch 4 (add --graph: one hipGraph replay per step); "
                          "cfg4: attention-gated AttU_Net(1,3) 496x768 batch 16; cfg5: volumetric UNet3D 64x512x512 batch 4 "
-                         "(BASELINE configs[3] / [4]; single GPU; --batch/--height/--width/--depth shrink them)")
+                         "(BASELINE configs[0] / [3] / [4]; single GPU; --batch/--height/--width/--depth shrink them)")
     ap.add_argument("--depth", type=int, default=64, help="cfg5: slices per volume")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+loss+backward as one HIP graph (no gain at batch 32: the queue never runs dry)")
@@ -290,7 +313,7 @@ def unet3d_train_flops(features, classes, d, h, w, in_ch=1):
 
 
 def side_config(args) -> int:
-    """cfg4 / cfg5 (BASELINE configs[3] / [4]): single GPU, same JSON contract; not the line the driver parses."""
+    """cfg1 / cfg4 / cfg5 (BASELINE configs[0] / [3] / [4]): single GPU, same JSON contract; not the line the driver parses."""
     import torch
     import torch.nn.functional as F
     from retinal_oct_image_segmentation_via_deep_learning_amd.optim import FusedSGD
@@ -298,7 +321,25 @@ def side_config(args) -> int:
     torch.cuda.set_device(0)
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1234)
-    if args.config == "cfg4":
+    if args.config == "cfg1":
+        from retinal_oct_image_segmentation_via_deep_learning_amd import ddp
+        from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment.BioNet_2020 import UNet as BioUNet
+        b = args.batch if args.batch != 32 else 4
+        h, w = (args.height, args.width) if (args.height, args.width) != (512, 1024) else (256, 256)
+        model = BioUNet(1, 2).to(dev).train()
+        x = torch.randn(b, 1, h, w, generator=g).to(dev)
+        t = torch.randint(0, 2, (b, h, w), generator=g).to(dev)
+        trainer = ddp.DataParallelTrainer(model, lr=0.01, momentum=0.9, use_graph=args.graph,
+                                          graph_warmup=max(1, min(2, args.warmup - 1)))
+        flops = bionet_train_flops(2, h, w)
+        unit, workload = "B-scans/s", (f"SOTAS/Layers_Segment BioNet_2020.UNet(1,2) train step, {h}x{w}, batch {b} "
+                                      f"(BASELINE configs[0], the reference's own CPU-runnable case)")
+        step_desc = ("fwd + CE loss + bwd + fused SGD(momentum), all on liboct_hip.so"
+                     + ("; the step is ONE hipGraph replay (launch-bound at this size)" if args.graph else ""))
+
+        def step():
+            return trainer.step(x, t)[0]
+    elif args.config == "cfg4":
         from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Lesions_Segment.SD_Layer_Net import AttU_Net
         b = args.batch if args.batch != 32 else 16
         h, w = (args.height, args.width) if (args.height, args.width) != (512, 1024) else (496, 768)
@@ -411,7 +452,7 @@ def worker(args) -> int:
 
     if args.config != "cfg2":
         if args.gpus != 1 or args.dry_run:
-            print("bench.py: --config cfg4 / cfg5 are single-GPU lines", file=sys.stderr)
+            print("bench.py: --config cfg1 / cfg4 / cfg5 are single-GPU lines", file=sys.stderr)
             return 2
         return side_config(args)
     backend = "gloo" if args.dry_run and args.backend == "nccl" and not torch.cuda.is_available() else args.backend
