@@ -335,7 +335,7 @@ def side_config(args) -> int:
         unit, workload = "B-scans/s", (f"SOTAS/Layers_Segment BioNet_2020.UNet(1,2) train step, {h}x{w}, batch {b} "
                                       f"(BASELINE configs[0], the reference's own CPU-runnable case)")
         step_desc = ("fwd + CE loss + bwd + fused SGD(momentum), all on liboct_hip.so"
-                     + ("; the step is ONE hipGraph replay (launch-bound at this size)" if args.graph else ""))
+                     + ("; the step is ONE hipGraph replay" if args.graph else ""))
 
         def step():
             return trainer.step(x, t)[0]
