@@ -25,6 +25,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -133,7 +134,14 @@ def launch_ranks(args) -> int:
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=rank == 0))
+
+    def relay(stream):      # ONE JSON line on stdout: anything else rank 0 (or a library under it) prints goes to stderr
+        for line in stream:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+    pump = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    pump.start()
     rc = 0
     pending = set(range(args.gpus))
     while pending:
@@ -148,6 +156,7 @@ def launch_ranks(args) -> int:
                 for o in pending:
                     procs[o].terminate()          # exactly the children started above
         time.sleep(0.05)
+    pump.join(timeout=10)
     return rc
 
 
@@ -460,6 +469,8 @@ def worker(args) -> int:
     if args.dry_run:
         return dry_run(args, rank, world)
 
+    if backend == "gloo" and torch.cuda.device_count() > 0:
+        local = local % torch.cuda.device_count()   # rehearsal on fewer GPUs than ranks: gloo lets ranks share a device (RCCL does not)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
