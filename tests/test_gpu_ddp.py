@@ -105,3 +105,22 @@ def test_rccl_group_runs_the_bucketed_exchange(tmp_path):
     torch.cuda.synchronize()
     ref = opt.flat_p.cpu().numpy()
     assert np.abs(r["p"] - ref).max() <= 3e-4 * np.abs(ref).max()    # fp32 atomics: summation order varies
+
+
+def test_bench_two_ranks_real_kernels_one_json_line():
+    """`bench.py --gpus 2` end to end with the real kernels: two self-spawned ranks (gloo, sharing the box's one GPU --
+    RCCL refuses that), broadcasts, bucketed exchange under backward, barrier + MAX-reduced time, and exactly ONE JSON
+    line on stdout that says n_gpus 2 and a global batch of 2 x the per-rank one."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--batch", "2", "--height", "64", "--width", "128", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and np.isfinite(out["loss"]) and len(out["config"]["grad_buckets_bytes"]) >= 1
