@@ -1,4 +1,4 @@
-"""A/B of the deferred-activation schedule on the SD_Layer_Net fixtures (f32 parity mode): per-tensor gradient errors against
+"""(diagnostic, not collected by pytest) A/B of the deferred-activation schedule on the SD_Layer_Net fixtures (f32 parity mode): per-tensor gradient errors against
 the reference fixture with OCT_LAZY-style settings.  Usage (GPU box): python tools/lazy_probe.py"""
 import os
 import sys
@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle.cases import bio_case  # noqa: E402

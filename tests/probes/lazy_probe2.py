@@ -1,7 +1,7 @@
 """which gradients differ between OCT_LAZY settings (SD U_Net fixture, f32 and bf16), in module order"""
 import os, sys
 import numpy as np, torch, torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle.cases import bio_case
 from retinal_oct_image_segmentation_via_deep_learning_amd import ops
