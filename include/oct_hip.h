@@ -352,8 +352,9 @@ int oct_affine_res_act_fwd(int dtype, const void* y, const float* scale, const f
 /* dz = dout * act'(z), from the stored output: relu [out>0], sigmoid out*(1-out). dz may alias dout */
 int oct_act_bwd(int dtype, const void* dout, const void* out, int act, void* dz, size_t n, void* stream);
 /* nn.MaxPool2d(k) on a materialised activation (SD_Layer_Net/unet.py:85, MGUNet_2021.py:211-217);
- * h, w must be multiples of k.  Backward writes all of da: dout to the first maximum of each
- * window in row-major order (ATen's tie rule), zero elsewhere.                                  */
+ * Output (n, h/k, w/k, c), torch's floor mode: trailing rows / columns that no whole window covers are
+ * ignored (MGR_Module's 3x3 / 5x5 pools, MGUNet_2021.py:163,168).  Backward writes all of da: dout to the
+ * first maximum of each window in row-major order (ATen's tie rule), zero elsewhere.            */
 int oct_maxpool_fwd(int dtype, const void* a, void* out, int n, int h, int w, int c, int k, void* stream);
 int oct_maxpool_bwd(int dtype, const void* a, const void* dout, void* da, int n, int h, int w, int c,
                     int k, void* stream);
@@ -364,6 +365,13 @@ int oct_bilinear_up_fwd(int dtype, const void* x, void* out, int n, int h, int w
                         void* stream);
 int oct_bilinear_up_bwd(int dtype, const void* dout, void* dx, int n, int h, int w, int c, int factor,
                         void* stream);
+/* F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True) (MGR_Module.forward,
+ * MGUNet_2021.py:180,184,188): x (n,h,w,c) -> out (n,ho,wo,c) for any output size; src = dst*(in-1)/(out-1),
+ * a one-pixel axis reads pixel 0.  Backward is the exact transpose (gather, deterministic).     */
+int oct_bilinear_resize_fwd(int dtype, const void* x, void* out, int n, int h, int w, int c, int ho, int wo,
+                            void* stream);
+int oct_bilinear_resize_bwd(int dtype, const void* dout, void* dx, int n, int h, int w, int c, int ho, int wo,
+                            void* stream);
 /* Scatter step of nn.ConvTranspose2d(kernel=s, stride=s) (MGUNet_2021.py:95, s=4): the GEMM output
  * in[n,h,w,(dy*s+dx)*cout+co] goes to out[n,h*s+dy,w*s+dx,co] (+ bias[co], may be NULL);
  * space_to_depth is its inverse, used on dOut before the weight / data gradients.               */

@@ -7,6 +7,8 @@ seeded default init:
 Pinned by tests/test_oracle_blocks.py against fixtures generated from the reference classes
 (tools/gen_golden_blocks.py).  Only tests/ may import this file.
 """
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
 
@@ -118,3 +120,95 @@ class U_Net(_SDNet):
 class AttU_Net(_SDNet):
     def __init__(self, img_ch=1, output_ch=1, channels=(64, 128, 256, 512, 1024)):
         super().__init__(img_ch, output_ch, list(channels), True, channels[0])
+
+
+# ---- MGU-Net: /root/reference/SOTAS/Layers_Segment/MGUNet_2021.py:29-39 (Basconv), :110-148 (GloRe_Unit), :150-194 (MGR_Module),
+# ---- :197-252 (MGUNet), :255-309 (MGUNet_2); pinned by tests/test_oracle_mgunet.py against tools/gen_golden_mgunet.py's fixtures
+class Basconv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding),
+                                  nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class GloRe_Unit(nn.Module):
+    """node features S, P = two 1x1 projections; adjacency = row-softmax(S P^T / sqrt(hw)); out = x + extend(adjacency P)"""
+
+    def __init__(self, in_channels, out_channels, kernel=1):
+        super().__init__()
+        self.conv_state = nn.Conv2d(in_channels, out_channels, 1)
+        self.conv_proj = nn.Conv2d(in_channels, out_channels, 1)
+        self.conv_extend = nn.Conv2d(out_channels, in_channels, 1)
+
+    def forward(self, x):
+        s, p = self.conv_state(x).flatten(2), self.conv_proj(x).flatten(2)          # [n, M, hw]
+        adj = torch.softmax(torch.einsum("nip,njp->nij", s, p) / (s.shape[2] ** 0.5), dim=2)
+        return x + self.conv_extend(torch.einsum("nij,njp->nip", adj, p).reshape(x.shape[0], -1, *x.shape[2:]))
+
+
+class MGR_Module(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        for i, (k, m) in enumerate(((1, out_channels), (2, out_channels), (3, out_channels // 2), (5, out_channels // 2))):
+            setattr(self, f"conv{i}_1", Basconv(in_channels, out_channels))
+            if i:
+                setattr(self, f"pool{i}", nn.MaxPool2d(kernel_size=[k, k], stride=k))
+                setattr(self, f"conv{i}_2", Basconv(out_channels, out_channels))
+            setattr(self, f"glou{i}", nn.Sequential(OrderedDict(GCN00=GloRe_Unit(out_channels, m))))
+        self.f1 = Basconv(4 * out_channels, in_channels, kernel_size=1, padding=0)
+
+    def forward(self, x):
+        outs = []
+        for i in range(4):
+            t = getattr(self, f"conv{i}_1")(x)
+            if i:
+                t = getattr(self, f"conv{i}_2")(getattr(self, f"pool{i}")(t))
+            t = getattr(self, f"glou{i}")(t)
+            outs.append(t if i == 0 else nn.functional.interpolate(t, size=x.shape[2:], mode="bilinear", align_corners=True))
+        return self.f1(torch.cat(outs, 1))
+
+
+class _MGNet(nn.Module):
+    POOLS = (2, 2, 2)
+
+    def __init__(self, in_channels=1, num_classes=11, feature_scale=4, is_deconv=True, is_batchnorm=True):
+        super().__init__()
+        f = [int(c / feature_scale) for c in (64, 128, 256, 512, 1024)]
+        cin = in_channels
+        for i, k in enumerate(self.POOLS):
+            setattr(self, f"conv{i + 1}", UnetConv(cin, f[i], is_batchnorm))
+            setattr(self, f"maxpool{i + 1}", nn.MaxPool2d(kernel_size=k))
+            cin = f[i]
+        self.mgb = MGR_Module(f[2], f[3])
+        self.center = UnetConv(f[2], f[3], is_batchnorm)
+        for i in (3, 2, 1):
+            setattr(self, f"up_concat{i}", (UnetUp4 if self.POOLS[i - 1] == 4 else UnetUp)(f[i], f[i - 1], is_deconv))
+        self.final_1 = nn.Conv2d(f[0], num_classes, 1)
+        for m in self.modules():       # kaiming-normal Conv2d weights, N(1, 0.02) BatchNorm weights / zero biases
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, a=0, mode="fan_in")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.normal_(m.weight, 1.0, 0.02)
+                nn.init.constant_(m.bias, 0.0)
+
+    def forward(self, x):
+        skips = []
+        for i in (1, 2, 3):
+            x = getattr(self, f"conv{i}")(x)
+            skips.append(x)
+            x = getattr(self, f"maxpool{i}")(x)
+        x = self.center(self.mgb(x))
+        for i in (3, 2, 1):
+            x = getattr(self, f"up_concat{i}")(x, skips[i - 1])
+        return self.final_1(x)
+
+
+class MGUNet(_MGNet):
+    POOLS = (2, 4, 4)
+
+
+class MGUNet_2(_MGNet):
+    POOLS = (2, 2, 2)

@@ -106,10 +106,10 @@ extern "C" int oct_act_bwd(int dtype, const void* dout, const void* out, int act
 // routes the gradient to the first maximum in row-major window order, like torch.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int V>
-__global__ void maxpool_fwd_kernel(const T* __restrict__ a, T* __restrict__ out, int n, int ho, int wo, int c, int k) {
+__global__ void maxpool_fwd_kernel(const T* __restrict__ a, T* __restrict__ out, int n, int h, int w, int c, int k) {
   const int G = c / V;
+  const int ho = h / k, wo = w / k;   // torch's floor mode: trailing rows / columns that no whole window covers are ignored
   const size_t total = (size_t)n * ho * wo * G;
-  const int w = wo * k, h = ho * k;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int g = i % G; size_t p = i / G;
     const int xo = p % wo; p /= wo; const int yo = p % ho; const int img = p / ho;
@@ -128,10 +128,10 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ a, T* __restrict__ out,
 }
 template <typename T, int V>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ a, const T* __restrict__ dout, T* __restrict__ da, int n,
-                                   int ho, int wo, int c, int k) {
+                                   int h, int w, int c, int k) {
   const int G = c / V;
+  const int ho = h / k, wo = w / k;
   const size_t total = (size_t)n * ho * wo * G;
-  const int w = wo * k, h = ho * k;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int g = i % G; size_t p = i / G;
     const int xo = p % wo; p /= wo; const int yo = p % ho; const int img = p / ho;
@@ -155,12 +155,12 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ a, const T* __restrict_
 }
 extern "C" int oct_maxpool_fwd(int dtype, const void* a, void* out, int n, int h, int w, int c, int k, void* stream) {
   OCT_CHECK(a && out && n > 0 && h > 0 && w > 0 && c > 0 && k >= 1, "oct_maxpool_fwd: bad args");
-  OCT_CHECK(h % k == 0 && w % k == 0, "oct_maxpool_fwd: %dx%d is not a multiple of the window %d", h, w, k);
+  OCT_CHECK(h >= k && w >= k, "oct_maxpool_fwd: %dx%d is smaller than the window %d", h, w, k);
   const int v = bk_vec(c);
   const int blocks = bk_blocks((size_t)n * (h / k) * (w / k) * (c / v));
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T, V) hipLaunchKernelGGL((maxpool_fwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)a, \
-                                        (T*)out, n, h / k, w / k, c, k)
+                                        (T*)out, n, h, w, c, k)
   BK_DISPATCH("oct_maxpool_fwd");
 #undef LAUNCH
   return oct_check_launch("maxpool_fwd");
@@ -168,12 +168,16 @@ extern "C" int oct_maxpool_fwd(int dtype, const void* a, void* out, int n, int h
 extern "C" int oct_maxpool_bwd(int dtype, const void* a, const void* dout, void* da, int n, int h, int w, int c, int k,
                                void* stream) {
   OCT_CHECK(a && dout && da && n > 0 && h > 0 && w > 0 && c > 0 && k >= 1, "oct_maxpool_bwd: bad args");
-  OCT_CHECK(h % k == 0 && w % k == 0, "oct_maxpool_bwd: %dx%d is not a multiple of the window %d", h, w, k);
+  OCT_CHECK(h >= k && w >= k, "oct_maxpool_bwd: %dx%d is smaller than the window %d", h, w, k);
   const int v = bk_vec(c);
   const int blocks = bk_blocks((size_t)n * (h / k) * (w / k) * (c / v));
   hipStream_t s = (hipStream_t)stream;
+  if (h % k || w % k) {   // floor mode: the rows / columns outside every window get no gradient
+    const size_t esz = dtype == OCT_DT_BF16 ? 2 : 4;
+    if (hipMemsetAsync(da, 0, (size_t)n * h * w * c * esz, s) != hipSuccess) { oct_set_error("oct_maxpool_bwd: memset failed"); return OCT_E_LAUNCH; }
+  }
 #define LAUNCH(T, V) hipLaunchKernelGGL((maxpool_bwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)a, \
-                                        (const T*)dout, (T*)da, n, h / k, w / k, c, k)
+                                        (const T*)dout, (T*)da, n, h, w, c, k)
   BK_DISPATCH("oct_maxpool_bwd");
 #undef LAUNCH
   return oct_check_launch("maxpool_bwd");
@@ -193,9 +197,9 @@ __device__ __forceinline__ void bil_src(int o, float r, int in, int& i0, int& i1
   l1 = s - (float)i0;
 }
 template <typename T, int V>
-__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int n, int h, int w, int c, int f,
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int n, int h, int w, int c, int ho, int wo,
                                     float ry, float rx) {
-  const int G = c / V, ho = h * f, wo = w * f;
+  const int G = c / V;
   const size_t total = (size_t)n * ho * wo * G;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int g = i % G; size_t p = i / G;
@@ -213,19 +217,20 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ out
   }
 }
 template <typename T, int V>
-__global__ void bilinear_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int n, int h, int w, int c, int f,
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int n, int h, int w, int c, int ho, int wo,
                                     float ry, float rx) {
-  const int G = c / V, ho = h * f, wo = w * f;
+  const int G = c / V;
   const size_t total = (size_t)n * h * w * G;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int g = i % G; size_t p = i / G;
     const int xi = p % w; p /= w; const int yi = p % h; const int img = p / h;
     // outputs that can touch input row yi have src = r*yo in (yi-1, yi+1); one row of slack either
     // side covers the rounding of the division, the exact test below uses the forward's own taps
-    const int ylo = h > 1 ? max(0, (int)floorf((float)(yi - 1) / ry) - 1) : 0;
-    const int yhi = h > 1 ? min(ho - 1, (int)ceilf((float)(yi + 1) / ry) + 1) : ho - 1;
-    const int xlo = w > 1 ? max(0, (int)floorf((float)(xi - 1) / rx) - 1) : 0;
-    const int xhi = w > 1 ? min(wo - 1, (int)ceilf((float)(xi + 1) / rx) + 1) : wo - 1;
+    // (ratio 0: a one-pixel input or output axis -- every output reads input 0, scan them all)
+    const int ylo = ry > 0.f ? max(0, (int)floorf((float)(yi - 1) / ry) - 1) : 0;
+    const int yhi = ry > 0.f ? min(ho - 1, (int)ceilf((float)(yi + 1) / ry) + 1) : ho - 1;
+    const int xlo = rx > 0.f ? max(0, (int)floorf((float)(xi - 1) / rx) - 1) : 0;
+    const int xhi = rx > 0.f ? min(wo - 1, (int)ceilf((float)(xi + 1) / rx) + 1) : wo - 1;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -249,29 +254,39 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dout, T* __restrict__ 
   }
 }
 static inline float bil_ratio(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
-extern "C" int oct_bilinear_up_fwd(int dtype, const void* x, void* out, int n, int h, int w, int c, int factor,
-                                   void* stream) {
-  OCT_CHECK(x && out && n > 0 && h > 0 && w > 0 && c > 0 && factor >= 1, "oct_bilinear_up_fwd: bad args");
+extern "C" int oct_bilinear_resize_fwd(int dtype, const void* x, void* out, int n, int h, int w, int c, int ho, int wo,
+                                       void* stream) {
+  OCT_CHECK(x && out && n > 0 && h > 0 && w > 0 && c > 0 && ho > 0 && wo > 0, "oct_bilinear_resize_fwd: bad args");
   const int v = bk_vec(c);
-  const int blocks = bk_blocks((size_t)n * h * factor * w * factor * (c / v));
+  const int blocks = bk_blocks((size_t)n * ho * wo * (c / v));
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T, V) hipLaunchKernelGGL((bilinear_fwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)x, \
-                                        (T*)out, n, h, w, c, factor, bil_ratio(h, h * factor), bil_ratio(w, w * factor))
-  BK_DISPATCH("oct_bilinear_up_fwd");
+                                        (T*)out, n, h, w, c, ho, wo, bil_ratio(h, ho), bil_ratio(w, wo))
+  BK_DISPATCH("oct_bilinear_resize_fwd");
 #undef LAUNCH
-  return oct_check_launch("bilinear_up_fwd");
+  return oct_check_launch("bilinear_resize_fwd");
 }
-extern "C" int oct_bilinear_up_bwd(int dtype, const void* dout, void* dx, int n, int h, int w, int c, int factor,
-                                   void* stream) {
-  OCT_CHECK(dout && dx && n > 0 && h > 0 && w > 0 && c > 0 && factor >= 1, "oct_bilinear_up_bwd: bad args");
+extern "C" int oct_bilinear_resize_bwd(int dtype, const void* dout, void* dx, int n, int h, int w, int c, int ho, int wo,
+                                       void* stream) {
+  OCT_CHECK(dout && dx && n > 0 && h > 0 && w > 0 && c > 0 && ho > 0 && wo > 0, "oct_bilinear_resize_bwd: bad args");
   const int v = bk_vec(c);
   const int blocks = bk_blocks((size_t)n * h * w * (c / v));
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T, V) hipLaunchKernelGGL((bilinear_bwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)dout, \
-                                        (T*)dx, n, h, w, c, factor, bil_ratio(h, h * factor), bil_ratio(w, w * factor))
-  BK_DISPATCH("oct_bilinear_up_bwd");
+                                        (T*)dx, n, h, w, c, ho, wo, bil_ratio(h, ho), bil_ratio(w, wo))
+  BK_DISPATCH("oct_bilinear_resize_bwd");
 #undef LAUNCH
-  return oct_check_launch("bilinear_up_bwd");
+  return oct_check_launch("bilinear_resize_bwd");
+}
+extern "C" int oct_bilinear_up_fwd(int dtype, const void* x, void* out, int n, int h, int w, int c, int factor,
+                                   void* stream) {
+  OCT_CHECK(factor >= 1, "oct_bilinear_up_fwd: bad args");
+  return oct_bilinear_resize_fwd(dtype, x, out, n, h, w, c, h * factor, w * factor, stream);
+}
+extern "C" int oct_bilinear_up_bwd(int dtype, const void* dout, void* dx, int n, int h, int w, int c, int factor,
+                                   void* stream) {
+  OCT_CHECK(factor >= 1, "oct_bilinear_up_bwd: bad args");
+  return oct_bilinear_resize_bwd(dtype, dout, dx, n, h, w, c, h * factor, w * factor, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

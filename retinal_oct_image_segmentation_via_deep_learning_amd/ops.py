@@ -203,6 +203,9 @@ class ConvAffineAct(torch.autograd.Function):
             else:
                 e._conv(src, wp, cout, taps, n, h, wd, y, stats=stats, **kd)
 
+        if train_bn and n * h * wd == 1:
+            # torch's batch_norm refuses a single value per channel in training mode (functional.py, _verify_batch_size)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {torch.Size([n, cout, h, wd])}")
         if train_bn:
             nblk = lib.oct_rowdot_blocks(n * h * wd, c0) if rowdot else e._stat_blocks(cout, n, h, wd, src, taps, **kd)
             partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
@@ -356,13 +359,15 @@ class ConvAffineAct(torch.autograd.Function):
 
 
 class MaxPool(torch.autograd.Function):
+    """nn.MaxPool2d(k) (stride k, torch's floor mode: trailing rows / columns that no whole window covers are ignored)."""
+
     @staticmethod
     def forward(ctx, dtype, k, a):
         e = kernels(dtype)
         a = a.contiguous()
         n, h, w, c = a.shape
-        if h % k or w % k:
-            raise RuntimeError(f"max-pool window {k} does not divide {h}x{w}")
+        if h < k or w < k:
+            raise RuntimeError(f"max-pool window {k} is larger than the {h}x{w} input")
         out = e._act(n, h // k, w // k, c, a.device)
         L.check(L.lib().oct_maxpool_fwd(e.dt, a.data_ptr(), out.data_ptr(), n, h, w, c, k, _stream()), "oct_maxpool_fwd")
         ctx.cfg = (dtype, k)
@@ -466,6 +471,32 @@ class BilinearUp(torch.autograd.Function):
         dx = e._act(n, h, w, c, dout.device)
         L.check(L.lib().oct_bilinear_up_bwd(e.dt, dout.data_ptr(), dx.data_ptr(), n, h, w, c, factor, _stream()),
                 "oct_bilinear_up_bwd")
+        return None, None, dx
+
+
+class BilinearResize(torch.autograd.Function):
+    """F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True) on NHWC (MGUNet_2021.py:180,184,188)."""
+
+    @staticmethod
+    def forward(ctx, dtype, size, x):
+        e = kernels(dtype)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        ho, wo = int(size[0]), int(size[1])
+        out = e._act(n, ho, wo, c, x.device)
+        L.check(L.lib().oct_bilinear_resize_fwd(e.dt, x.data_ptr(), out.data_ptr(), n, h, w, c, ho, wo, _stream()),
+                "oct_bilinear_resize_fwd")
+        ctx.cfg = (dtype, (ho, wo), (n, h, w, c))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dtype, (ho, wo), (n, h, w, c) = ctx.cfg
+        e = kernels(dtype)
+        dout = dout.contiguous()
+        dx = e._act(n, h, w, c, dout.device)
+        L.check(L.lib().oct_bilinear_resize_bwd(e.dt, dout.data_ptr(), dx.data_ptr(), n, h, w, c, ho, wo, _stream()),
+                "oct_bilinear_resize_bwd")
         return None, None, dx
 
 

@@ -102,7 +102,8 @@ def block_case(name, make, in_shapes, seed, init=None, thresh=2e-5):
     print(f"{name}: seed {seed} min|relu in| {z:.2e} out {tuple(out.shape)}")
 
 
-def net_case(name, cls, seed, n, cin, ncls, h, w, thresh, full_weights):
+def net_case(name, cls, seed, n, cin, ncls, h, w, thresh, full_weights, compact=False):
+    """compact: logits as sum / abs-sum / every 97th element / arg-max map instead of the full float64 tensors."""
     while True:
         m, x, t = bio_case(cls, seed, n, cin, ncls, h, w)
         z = relu_margin(m, x)
@@ -124,7 +125,14 @@ def net_case(name, cls, seed, n, cin, ncls, h, w, thresh, full_weights):
     logits = m(x.double())
     loss = F.cross_entropy(logits, t)
     loss.backward()
-    rec["logits"] = logits.detach().numpy()
+    def put(key, v):
+        if compact:
+            rec[key + "_sample"] = v.reshape(-1)[::97].copy()
+            rec[key + "_sums"] = np.array([v.sum(), np.abs(v).sum()])
+            rec[key + "_argmax"] = v.argmax(1).astype(np.uint8)
+        else:
+            rec[key] = v
+    put("logits", logits.detach().numpy())
     rec["loss"] = np.array([loss.item()])
     for k, p in m.named_parameters():
         gr = p.grad.numpy()
@@ -138,7 +146,7 @@ def net_case(name, cls, seed, n, cin, ncls, h, w, thresh, full_weights):
             rec["b1/" + k] = v.numpy()
     m.eval()
     with torch.no_grad():
-        rec["logits_eval"] = m(x.double()).numpy()
+        put("logits_eval", m(x.double()).numpy())
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **rec)
     print(f"{name}: seed {seed} loss {loss.item():.6f} min|relu in| {z:.2e} margin {margin:.2e} "
