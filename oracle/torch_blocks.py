@@ -85,11 +85,12 @@ class Attention_block(nn.Module):
 class _SDNet(nn.Module):
     def __init__(self, img_ch, output_ch, channels, gates, head_in):
         super().__init__()
+        self._n = len(channels)
         self.Maxpool = nn.MaxPool2d(2, 2)
         self.Conv1 = conv_block(img_ch, channels[0])
-        for i in range(1, 5):
+        for i in range(1, self._n):
             setattr(self, f"Conv{i + 1}", conv_block(channels[i - 1], channels[i]))
-        for i in (5, 4, 3, 2):
+        for i in range(self._n, 1, -1):
             setattr(self, f"Up{i}", up_conv(channels[i - 1], channels[i - 2]))
             if gates:
                 setattr(self, f"Att{i}", Attention_block(channels[i - 2], channels[i - 2], channels[i - 2] // 2))
@@ -99,11 +100,11 @@ class _SDNet(nn.Module):
 
     def forward(self, x):
         feats = []
-        for i in range(1, 6):
+        for i in range(1, self._n + 1):
             x = getattr(self, f"Conv{i}")(x if i == 1 else self.Maxpool(x))
             feats.append(x)
         d = feats[-1]
-        for i in (5, 4, 3, 2):
+        for i in range(self._n, 1, -1):
             d = getattr(self, f"Up{i}")(d)
             skip = feats[i - 2]
             if self._gates:
@@ -119,6 +120,11 @@ class U_Net(_SDNet):
 
 class AttU_Net(_SDNet):
     def __init__(self, img_ch=1, output_ch=1, channels=(64, 128, 256, 512, 1024)):
+        super().__init__(img_ch, output_ch, list(channels), True, channels[0])
+
+
+class AttU_Net4(_SDNet):      # SD_Layer_Net/unet.py:153-214: four levels
+    def __init__(self, img_ch=1, output_ch=1, channels=(64, 128, 256, 512)):
         super().__init__(img_ch, output_ch, list(channels), True, channels[0])
 
 

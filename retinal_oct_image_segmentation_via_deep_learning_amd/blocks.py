@@ -320,3 +320,25 @@ class AttU_Net(_SDUNetBase):
                                                      F_int=channels[i - 2] // 2, compute_dtype=compute_dtype))
             setattr(self, f"Up_conv{i}", conv_block(ch_in=channels[i - 1], ch_out=channels[i - 2], **kw))
         self.Conv_1x1 = nn.Conv2d(channels[0], output_ch, kernel_size=1, stride=1, padding=0)
+
+
+class AttU_Net4(_SDUNetBase):
+    """SD_Layer_Net/unet.py:153-214: the four-level attention-gated U-Net (three poolings, channels 64..512)."""
+    _levels = 4
+
+    def __init__(self, img_ch=1, output_ch=1, channels=[64, 128, 256, 512], act=None, drop_rate=0.0, compute_dtype="bf16"):
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        if act is None:
+            act = nn.ReLU
+        kw = dict(act=act, drop_rate=drop_rate, compute_dtype=compute_dtype)
+        self.Maxpool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.Conv1 = conv_block(ch_in=img_ch, ch_out=channels[0], **kw)
+        for i in range(1, 4):
+            setattr(self, f"Conv{i + 1}", conv_block(ch_in=channels[i - 1], ch_out=channels[i], **kw))
+        for i in (4, 3, 2):
+            setattr(self, f"Up{i}", up_conv(ch_in=channels[i - 1], ch_out=channels[i - 2], **kw))
+            setattr(self, f"Att{i}", Attention_block(F_g=channels[i - 2], F_l=channels[i - 2],
+                                                     F_int=channels[i - 2] // 2, compute_dtype=compute_dtype))
+            setattr(self, f"Up_conv{i}", conv_block(ch_in=channels[i - 1], ch_out=channels[i - 2], **kw))
+        self.Conv_1x1 = nn.Conv2d(channels[0], output_ch, kernel_size=1, stride=1, padding=0)

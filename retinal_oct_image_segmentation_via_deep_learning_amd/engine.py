@@ -173,6 +173,7 @@ class UNetEngine:
         self.deterministic = os.environ.get("OCT_DETERMINISTIC", "0") == "1"
         self.debug = None  # set to a dict to capture intermediate gradients (tests / probes)
         self.prof = None   # set to a list: (kind, start_event, end_event) around every MFMA launch
+        self.prof_labels = None   # set to a list next to `prof`: (taps, cin, cout, n, h, w, in/dy mode, out mode) per launch
 
     def set_dtype(self, dtype: str) -> None:
         if dtype not in ("bf16", "f32"):
@@ -191,11 +192,13 @@ class UNetEngine:
         ev.record()  # torch's current stream == the stream the kernel is launched on
         return ev
 
-    def _prof_end(self, ev, kind):
+    def _prof_end(self, ev, kind, label=None):
         if ev is not None:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
             self.prof.append((kind, ev, end))
+            if self.prof_labels is not None:
+                self.prof_labels.append(label)
 
     def _const(self, value: float, n: int, dev):
         key = (float(value), int(n), str(dev))
@@ -264,7 +267,7 @@ class UNetEngine:
                        L.ptr(wpacked), L.ptr(bias), L.ptr(y0), L.ptr(y1), L.ptr(stats))
         ev = self._prof_begin()
         L.check(L.lib().oct_conv_forward(C.byref(d), C.byref(a), _stream()), "oct_conv_forward")
-        self._prof_end(ev, "igemm")
+        self._prof_end(ev, "igemm", (taps, src.channels, cout, n, h, w, in_mode, out_mode))
 
     def _stat_blocks(self, cout, n, h, w, src: Src, taps=9, kh=0, kw=0, depth=0):
         """rows of the partial-statistics buffer the conv with this exact descriptor will write"""
@@ -298,7 +301,7 @@ class UNetEngine:
                                                                  else [None, None, None, None]), L.ptr(bias_parts))
         ev = self._prof_begin()
         L.check(L.lib().oct_conv_wgrad(C.byref(d), C.byref(a), _stream()), "oct_conv_wgrad")
-        self._prof_end(ev, "wgrad")
+        self._prof_end(ev, "wgrad", (taps, ktot, cout, n, h, w, dy_mode, 0))
         if bias_parts is not None:     # the caller zeroed dbias (atomics contract): add the ordered sum to it
             L.check(L.lib().oct_reduce_bias_partials(bias_parts.data_ptr(), nparts, cout,
                                                      cout // 4 if dy_mode == L.IN_S2D else cout, dbias.data_ptr(), 1,

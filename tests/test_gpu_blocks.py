@@ -72,7 +72,8 @@ def test_bf16_block_is_close(golden_dir, name):
     assert min(cos) > 0.9, (name, cos)
 
 
-NETS = [("attunet_c3_2x32x48", "AttU_Net", dict(channels=[4, 8, 16, 32, 64])), ("sd_unet_c2_1x32x32", "U_Net", {})]
+NETS = [("attunet_c3_2x32x48", "AttU_Net", dict(channels=[4, 8, 16, 32, 64])), ("sd_unet_c2_1x32x32", "U_Net", {}),
+        ("attunet4_c3_2x24x40", "AttU_Net4", dict(channels=[4, 8, 16, 32]))]
 
 
 @pytest.mark.parametrize("name,cls,kw", NETS)
@@ -99,7 +100,7 @@ def test_f32_network_matches_reference_fixture(golden_dir, name, cls, kw):
     with torch.no_grad():
         close(m(x.cuda()).cpu().numpy(), z["logits_eval"], "logits_eval", 2e-5, 1.0)
     with pytest.raises(RuntimeError):
-        m(torch.zeros(1, cin, 24, 32, device="cuda"))       # not divisible by 16: the reference raises too
+        m(torch.zeros(1, cin, 20, 36, device="cuda"))       # not divisible by 16 (8 for AttU_Net4): the reference raises too
 
 
 def test_bf16_attunet_tracks_reference(golden_dir):

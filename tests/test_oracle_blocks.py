@@ -51,6 +51,7 @@ def test_block_restatement_matches_reference_fixture(golden_dir, name):
 
 
 @pytest.mark.parametrize("name,cls", [("attunet_c3_2x32x48", lambda ci, nc: TB.AttU_Net(ci, nc, channels=[4, 8, 16, 32, 64])),
+                                      ("attunet4_c3_2x24x40", lambda ci, nc: TB.AttU_Net4(ci, nc, channels=[4, 8, 16, 32])),
                                       ("sd_unet_c2_1x32x32", lambda ci, nc: TB.U_Net(ci, nc))])
 def test_network_restatement_matches_reference_fixture(golden_dir, name, cls):
     z = np.load(os.path.join(golden_dir, name + ".npz"))

@@ -187,6 +187,8 @@ def main():
     init_case()
     net_case("attunet_c3_2x32x48", lambda ci, nc: ref_sd.AttU_Net(ci, nc, channels=[4, 8, 16, 32, 64]), 400,
              2, 1, 3, 32, 48, thresh=1e-5, full_weights=True)
+    net_case("attunet4_c3_2x24x40", lambda ci, nc: ref_sd.AttU_Net4(ci, nc, channels=[4, 8, 16, 32]), 450,
+             2, 1, 3, 24, 40, thresh=1e-5, full_weights=True)
     net_case("sd_unet_c2_1x32x32", lambda ci, nc: ref_sd.U_Net(ci, nc), 500, 1, 1, 2, 32, 32, thresh=5e-6,
              full_weights=False)
     # negative: AttU_Net as shipped raises TypeError at construction (unet.py:92)
