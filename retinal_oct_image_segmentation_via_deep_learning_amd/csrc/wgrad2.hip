@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   constexpr int INB = NPI * 64, DYB = NPD * 64;        // bytes per 32-channel block
   constexpr int STAGEB = IB * INB + CB * DYB;
   constexpr int PAIRS = CB * IB, PS = 4 / PAIRS, ROWS = TH / PS;
-  static_assert(PAIRS == 1 || PAIRS == 4, "1 or 4 channel-block pairs per workgroup");
+  static_assert(PAIRS == 1 || PAIRS == 2 || PAIRS == 4, "1, 2 or 4 channel-block pairs per workgroup");
   typedef Mma<bf16_t> M;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     if (t0 >= t1) return;
     nstage = t1 - t0;
   }
-  constexpr int DRING = ((CB * IB == 4 && TH == 8) || TH == 16) ? 2 : 4;   // stages of loads in flight per producer thread (register budget)
+  constexpr int DRING = ((CB * IB >= 2 && TH == 8) || TH == 16) ? 2 : 4;   // stages of loads in flight per producer thread (register budget)
   const int nstage_pad = (nstage + DRING - 1) / DRING * DRING;
 
   // BN scale/shift of this workgroup's input channels in LDS (kept off the in-order vmcnt queue)
@@ -465,7 +465,15 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
     // 64 x 64 channel blocks: 8-row tiles (halo overhead 10/8 instead of 6/4 on the staged input, half the
     // barriers; the two 76-KB stage buffers fill the LDS and the producer ring drops to 2 stages): -5 %
     // 32 x 32 channel blocks (the 32-channel full-resolution layers): 16-row tiles, halo overhead 18/16 -- -6 %
-    if (big) launch_w2<9, 2, 2, 8>(p, nco, nci, s); else launch_w2<9, 1, 1, 16>(p, nco, nci, s);
+    // 32 x 64 / 64 x 32 channel blocks (an odd block count on one side: Cout = 32 with Cin = 64, Cin = 32 with Cout = 64 --
+    // dec1 conv1, enc2 conv1): two pairs per workgroup share the staged tile of the 32-channel side, which 1 x 1 blocks
+    // read twice (the 64 -> 32 layer at 512 x 1024: 4.3 GB per launch instead of 3.2)
+    static int pairs2 = -1;
+    if (pairs2 < 0) { const char* e = getenv("OCT_W2_PAIRS2"); pairs2 = (e && e[0] == '0') ? 0 : 1; }
+    if (big) launch_w2<9, 2, 2, 8>(p, nco, nci, s);
+    else if (pairs2 && nci % 2 == 0 && (d->h % 8) == 0 && d->depth == 0 && d->dy_img_mul == 0) launch_w2<9, 1, 2, 8>(p, nco, nci, s);
+    else if (pairs2 && nco % 2 == 0 && (d->h % 8) == 0 && d->depth == 0 && d->dy_img_mul == 0) launch_w2<9, 2, 1, 8>(p, nco, nci, s);
+    else launch_w2<9, 1, 1, 16>(p, nco, nci, s);
   } else {
     if (big) launch_w2<1, 2, 2, 8>(p, nco, nci, s); else launch_w2<1, 1, 1, 8>(p, nco, nci, s);   // 8 rows: -14 % vs 4
   }
