@@ -74,8 +74,16 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   constexpr int NPI = LH * LW, NPD = TH * TW;          // pixels of the input / dY tile
   constexpr int INB = NPI * 64, DYB = NPD * 64;        // bytes per 32-channel block
   constexpr int STAGEB = IB * INB + CB * DYB;
-  constexpr int PAIRS = CB * IB, PS = 4 / PAIRS, ROWS = TH / PS;
-  static_assert(PAIRS == 1 || PAIRS == 2 || PAIRS == 4, "1, 2 or 4 channel-block pairs per workgroup");
+  // MULTI (1 x 1 kernels only: one accumulator per pair, 16 registers): 8 or 16 pairs per workgroup, the four waves as a
+  // 2 x 2 grid over (co, ci), each owning WCB x WIB pairs of the same staged tile.  A 1 x 1 weight gradient is a plain GEMM
+  // over the pixels with nothing but staging between memory and the matrix pipe: with 64 x 64 blocks the deep transposed
+  // convolutions staged their input 16x and dY 8x (upconv4: 2.1 GB for a 0.2 GB problem, 0.29 ms) -- 128 x 128 halves both.
+  constexpr int PAIRS = CB * IB;
+  constexpr bool MULTI = PAIRS > 4;
+  constexpr int WCB = MULTI ? CB / 2 : 1, WIB = MULTI ? IB / 2 : 1;
+  constexpr int PS = MULTI ? 1 : 4 / PAIRS, ROWS = TH / PS;
+  static_assert(PAIRS == 1 || PAIRS == 2 || PAIRS == 4 || (TAPS == 1 && CB == 4 && (IB == 2 || IB == 4)),
+                "1, 2 or 4 channel-block pairs per workgroup (1 x 1: also 4 x 2 and 4 x 4)");
   typedef Mma<bf16_t> M;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -92,7 +100,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     if (t0 >= t1) return;
     nstage = t1 - t0;
   }
-  constexpr int DRING = ((CB * IB >= 2 && TH == 8) || TH == 16) ? 2 : 4;   // stages of loads in flight per producer thread (register budget)
+  constexpr int DRING = ((CB * IB >= 2 && TH == 8) || TH == 16 || MULTI) ? 2 : 4;   // stages of loads in flight per producer thread (register budget)
   const int nstage_pad = (nstage + DRING - 1) / DRING * DRING;
 
   // BN scale/shift of this workgroup's input channels in LDS (kept off the in-order vmcnt queue)
@@ -267,22 +275,27 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
 
   // ================================ MFMA waves ================================
   __builtin_amdgcn_s_setprio(3);  // win issue arbitration against the co-resident producer wave
-  const int pair = wave % PAIRS, psx = wave / PAIRS;
-  const int cb = pair / IB, ib = pair % IB;
+  const int pair = MULTI ? 0 : wave % PAIRS, psx = MULTI ? 0 : wave / PAIRS;
+  const int cb = MULTI ? (wave >> 1) * WCB : pair / IB, ib = MULTI ? (wave & 1) * WIB : pair % IB;   // MULTI: first pair of the wave's sub-block
   const int g4 = lane >> 4, li = lane & 15;
   // transposed-read lane address inside a [pixel][64 B] block: pixel 8*(g4>>1) + (li>>2), channel 16*(g4&1) + 4*(li&3)
   const int lane_off = (8 * (g4 >> 1) + (li >> 2)) * 64 + (16 * (g4 & 1) + 4 * (li & 3)) * 2;
 
-  f32x16 acc[TAPS];
+  constexpr int NACC = MULTI ? WCB * WIB : TAPS;
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   // bias gradient = sum over pixels of dY: one more MFMA per k-step against an all-ones operand
   const bool do_bias = (p.dbias != nullptr) && (ib == 0) && (blockIdx.z == 0);
-  f32x16 accb;
+  f32x16 accb, accb2[MULTI ? WCB : 1];   // MULTI: one bias accumulator per co block of the wave
 #pragma unroll
   for (int i = 0; i < 16; ++i) accb[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < (MULTI ? WCB : 1); ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accb2[j][i] = 0.f;
   bf16x8 ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
@@ -339,6 +352,30 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
             M::mma(acc[ty * 3 + tx], aw[k & 3][h], bq[j % (LA + 1)]);
           }
         }
+    } else if constexpr (MULTI) {
+      // per 16-pixel k-step: WCB dY fragments x WIB input fragments -> WCB * WIB MFMAs, the fragments of step k + 1 read
+      // while step k multiplies
+      bf16x8 af[2][WCB], bf[2][WIB];
+#pragma unroll
+      for (int j = 0; j < WCB; ++j) af[0][j] = tr_frag(dy_t + j * DYB + a_off(0));
+#pragma unroll
+      for (int i = 0; i < WIB; ++i) bf[0][i] = tr_frag(in_t + i * INB + b_off(0, 0));
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        if (k + 1 < NK) {
+#pragma unroll
+          for (int j = 0; j < WCB; ++j) af[(k + 1) & 1][j] = tr_frag(dy_t + j * DYB + a_off(k + 1));
+#pragma unroll
+          for (int i = 0; i < WIB; ++i) bf[(k + 1) & 1][i] = tr_frag(in_t + i * INB + b_off(k + 1, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < WCB; ++j) {
+          if (do_bias) M::mma(accb2[j], af[k & 1][j], ones);
+#pragma unroll
+          for (int i = 0; i < WIB; ++i) M::mma(acc[j * WIB + i], af[k & 1][j], bf[k & 1][i]);
+        }
+      }
     } else {
       constexpr int NSEQ = NK * TAPS;
       bf16x8 bq[3];
@@ -365,9 +402,33 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
 
   // D[row = co][col = ci]
   const int r = lane & 31, hh = lane >> 5;
-  const int ci = ci_sb + ib * 32 + r;
   const int slab = blockIdx.x * PS + psx;
   float* const out = p.dwp + (p.part_mode ? (size_t)slab * p.slab_elems : 0);
+  const int cr = (p.dy_mode == OCT_IN_S2D) ? (p.cout >> 2) : p.cout;
+  if constexpr (MULTI) {
+#pragma unroll
+    for (int j = 0; j < WCB; ++j) {
+#pragma unroll
+      for (int ii = 0; ii < WIB; ++ii) {
+        const int ci = ci_sb + (ib + ii) * 32 + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = co_sb + (cb + j) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          float* const q = &out[(size_t)co * p.ktot + ci];
+          if (p.part_mode) *q = acc[j * WIB + ii][i]; else atomicAdd(q, acc[j * WIB + ii][i]);
+        }
+      }
+      if (do_bias && r == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = co_sb + (cb + j) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (p.part_mode) p.dbias_part[(size_t)slab * p.cout + co] = accb2[j][i];
+          else atomicAdd(&p.dbias[co % cr], accb2[j][i]);
+        }
+      }
+    }
+  } else {
+  const int ci = ci_sb + ib * 32 + r;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -377,13 +438,13 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       if (p.part_mode) *q = acc[t][i]; else atomicAdd(q, acc[t][i]);
     }
   if (do_bias && r == 0) {
-    const int cr = (p.dy_mode == OCT_IN_S2D) ? (p.cout >> 2) : p.cout;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = co_sb + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
       if (p.part_mode) p.dbias_part[(size_t)slab * p.cout + co] = accb[i];
       else atomicAdd(&p.dbias[co % cr], accb[i]);
     }
+  }
   }
 #ifdef OCT_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -416,7 +477,7 @@ static void launch_w2r(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   p.per_wg = (p.ntiles + gx - 1) / gx;
   p.interleave = p.ntiles >= 2 * gx ? 1 : 0;
   if (!p.interleave) gx = (p.ntiles + p.per_wg - 1) / p.per_wg;
-  if (p.part_mode < 0) { p.part_mode = gx * (4 / (CB * IB)); return; }   // query: slabs this launch would write
+  if (p.part_mode < 0) { p.part_mode = gx * (CB * IB > 4 ? 1 : 4 / (CB * IB)); return; }   // query: slabs this launch would write
   hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH, RAGGED, D3>), dim3(gx, gy, gz), dim3(512), lds, s, p);
 }
 template <int TAPS, int CB, int IB, int TH>
@@ -475,7 +536,13 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
     else if (pairs2 && nco % 2 == 0 && (d->h % 8) == 0 && d->depth == 0 && d->dy_img_mul == 0) launch_w2<9, 2, 1, 8>(p, nco, nci, s);
     else launch_w2<9, 1, 1, 16>(p, nco, nci, s);
   } else {
-    if (big) launch_w2<1, 2, 2, 8>(p, nco, nci, s); else launch_w2<1, 1, 1, 8>(p, nco, nci, s);   // 8 rows: -14 % vs 4
+    static int multi = -1;
+    if (multi < 0) { const char* e = getenv("OCT_W2_MULTI"); multi = (e && e[0] == '0') ? 0 : 1; }
+    const bool m_ok = multi && nco % 4 == 0 && (d->h % 4) == 0 && d->depth == 0 && d->dy_img_mul == 0;
+    if (m_ok && nci % 4 == 0) launch_w2<1, 4, 4, 4>(p, nco, nci, s);        // 128 x 128 channel blocks, 4-row tiles
+    else if (m_ok && nci % 2 == 0) launch_w2<1, 4, 2, 4>(p, nco, nci, s);   // 128 x 64 (upconv1: Cin = 64)
+    else if (big) launch_w2<1, 2, 2, 8>(p, nco, nci, s);
+    else launch_w2<1, 1, 1, 8>(p, nco, nci, s);   // 8 rows: -14 % vs 4
   }
   if (query) { *query = p.part_mode; return 1; }
   int rc = oct_check_launch("wgrad2");

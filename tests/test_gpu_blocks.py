@@ -236,9 +236,9 @@ def test_deferred_activation_schedule_is_bit_identical_to_the_materialised_one(d
                                 **{"b/" + k: v.clone() for k, v in m.state_dict().items() if "running" in k})
     finally:
         e.deterministic, ops.LAZY[0] = keep_det, keep_lazy
-    # (two bias gradients go through oct_channel_sum's atomics -- convolutions without BN whose Cin is not a multiple of
+    # (these bias gradients go through oct_channel_sum's atomics -- convolutions without BN whose Cin is not a multiple of
     # 32 -- and are equal up to summation order)
-    loose = ("Conv_1x1.bias", "Conv1.init_conv.bias")
+    loose = ("Conv_1x1.bias", "Conv1.init_conv.bias", "Conv2.init_conv.bias")   # Conv2: Cin = 16 in the narrow AttU_Net case
     bad = [k for k in res[True] if not (torch.allclose(res[True][k], res[False][k], rtol=1e-4, atol=1e-7)
                                         if k in loose else torch.equal(res[True][k], res[False][k]))]
     assert bad == [], bad
