@@ -207,6 +207,135 @@ __global__ void __launch_bounds__(256) first_fprop_kernel(const bf16_t* __restri
   }
 }
 
+// fprop on the matrix pipe (W % 32 == 0): a wave owns 32 consecutive pixels of one image row.  The stencil kernels above are
+// bound by vector-instruction throughput (~160 instructions per pixel and 8-channel group: 72 FMAs, nine 2-byte loads with
+// their bounds logic; the 3-D one 216 FMAs and 27 loads), not by their 64 B per pixel of output.  Here the K = 9 (27) taps
+// are one (two) k16 steps of v_mfma_f32_32x32x16_bf16 padded with zeros: per 32 pixels a lane loads 8 (16) input values --
+// row and slice validity are wave-uniform, only the two end lanes of a row test x -- packs them into the B fragment and one
+// (two) MFMA per 32 output channels replace 9,216 (27,648) FMAs; the epilogue is igemm2's (bf16 pack, wave-private LDS
+// transpose, 16-byte NHWC stores, BatchNorm sums in registers).
+template <int F, int KD>
+__global__ void __launch_bounds__(256) first_fprop_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                               bf16_t* __restrict__ y, float* __restrict__ stats, int n,
+                                                               int h, int w, int depth) {
+  constexpr int NTAP = 9 * KD, KS = (NTAP + 15) / 16, NB = F / 32, NV = 8 * KS;
+  typedef Mma<bf16_t> M;
+  __shared__ __attribute__((aligned(16))) unsigned char scr[4][32 * 80];
+  __shared__ float red[4][2][F];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  // A fragments (filters): lane = (output channel r of the block, k half hh), k = tap index T = kd*9 + kh*3 + kw
+  bf16x8 afr[NB][KS];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int T = 16 * ks + 8 * hh + j;
+        const int kd = T / 9, t = T - 9 * kd;
+        afr[cb][ks][j] = T < NTAP ? wp[(cb * 9 + t) * 512 + r * 8 + (KD == 3 ? kd : 0)] : (bf16_t)0.0f;
+      }
+  // this lane's taps: element offset from the pixel and the (dz, dy, dx) class of each
+  int toff[NV];
+  unsigned tcls[NV];   // bits 0-1 dz+1, 2-3 dy+1, 4-5 dx+1, bit 6 dead (zero padding of K)
+  const int plane = h * w;
+#pragma unroll
+  for (int jj = 0; jj < NV; ++jj) {
+    const int T = 16 * (jj / 8) + 8 * hh + (jj % 8);
+    const int kd = T / 9, t = T - 9 * kd;
+    const int dz = KD == 3 ? kd - 1 : 0, dy = t / 3 - 1, dx = t % 3 - 1;
+    toff[jj] = dz * plane + dy * w + dx;
+    tcls[jj] = T < NTAP ? (unsigned)((dz + 1) | ((dy + 1) << 2) | ((dx + 1) << 4)) : 64u;
+  }
+  float s1[NB][16], s2[NB][16];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1[cb][i] = 0.f; s2[cb][i] = 0.f; }
+
+  const unsigned ngroups = ((unsigned)n * h * w) >> 5, gstride = gridDim.x * 4;
+  auto gather = [&](unsigned g, unsigned short (&v)[NV]) {
+    const unsigned q0 = g << 5;
+    const unsigned row = q0 / (unsigned)w;
+    const int x0 = (int)(q0 - row * (unsigned)w), yy = (int)(row % (unsigned)h);
+    const int zz = KD == 3 ? (int)((row / (unsigned)h) % (unsigned)depth) : 0;
+    // validity masks, bit c = class c valid: slice and row wave-uniform, column per lane
+    const unsigned zm = KD == 3 ? ((zz > 0 ? 1u : 0u) | 2u | (zz + 1 < depth ? 4u : 0u)) : 2u;
+    const unsigned ym = (yy > 0 ? 1u : 0u) | 2u | (yy + 1 < h ? 4u : 0u);
+    const int xx = x0 + r;
+    const unsigned xm = (xx > 0 ? 1u : 0u) | 2u | (xx + 1 < w ? 4u : 0u);
+    const unsigned q = q0 + (unsigned)r;
+#pragma unroll
+    for (int jj = 0; jj < NV; ++jj) {
+      const unsigned c = tcls[jj];
+      const bool ok = (c & 64u) == 0 && ((zm >> (c & 3u)) & (ym >> ((c >> 2) & 3u)) & (xm >> ((c >> 4) & 3u)) & 1u) != 0;
+      const unsigned short val = reinterpret_cast<const unsigned short*>(x)[ok ? (int)q + toff[jj] : (int)q];
+      v[jj] = ok ? val : (unsigned short)0;
+    }
+  };
+  unsigned g = blockIdx.x * 4 + wave;
+  unsigned short vn[NV];
+  gather(g < ngroups ? g : 0u, vn);
+  unsigned char* const sc = scr[wave];
+  for (; g < ngroups; g += gstride) {
+    bf16x8 bfr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+      u16x8 t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = vn[8 * ks + j];
+      bfr[ks] = __builtin_bit_cast(bf16x8, t);
+    }
+    gather(g + gstride < ngroups ? g + gstride : g, vn);   // next group's taps in flight under this one's epilogue
+    const size_t q0 = (size_t)g << 5;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      f32x16 acc;
+      M::mma0(acc, afr[cb][0], bfr[0]);
+#pragma unroll
+      for (int ks = 1; ks < KS; ++ks) M::mma(acc, afr[cb][ks], bfr[ks]);
+      // D[row = channel][col = pixel]: lane = pixel r, registers = channels (i&3) + 8*(i>>2) + 4*hh of the block
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const u32x2 pk = {f1_pack(acc[4 * gq], acc[4 * gq + 1]), f1_pack(acc[4 * gq + 2], acc[4 * gq + 3])};
+        *reinterpret_cast<u32x2*>(sc + r * 80 + (8 * gq + 4 * hh) * 2) = pk;
+      }
+      if (stats) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s1[cb][i] += acc[i]; s2[cb][i] = fmaf(acc[i], acc[i], s2[cb][i]); }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int chunk = lane + 64 * k;   // 128 chunks of 16 B: pixel = chunk / 4, part = chunk % 4
+        const u32x4 tv = *reinterpret_cast<const u32x4*>(sc + (chunk >> 2) * 80 + (chunk & 3) * 16);
+        *reinterpret_cast<u32x4*>(y + (q0 + (chunk >> 2)) * F + cb * 32 + (chunk & 3) * 8) = tv;
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const float t1 = reduce32_scatter16(s1[cb], lane);
+      const float t2 = reduce32_scatter16(s2[cb], lane);
+      if ((lane & 1) == 0) {
+        const int reg = scatter16_reg_of_lane(lane);
+        const int cl = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        red[wave][0][cl] = t1;
+        red[wave][1][cl] = t2;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * F; i += 256) {
+      const int st = i / F, c = i % F;
+      stats[((size_t)blockIdx.x * 2 + st) * F + c] = red[0][st][c] + red[1][st][c] + red[2][st][c] + red[3][st][c];
+    }
+  }
+}
+
 // wgrad: the same (pixel, 8-channel group) mapping, 72 register accumulators, one LDS + atomic
 // reduction per workgroup; dY (and y for the fused BN-backward apply) of the next pixel are in flight
 // while the current one is accumulated.
@@ -322,6 +451,18 @@ int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
   const int grid = first_grid(d);
   hipStream_t s = as_stream(stream);
   float* st = d->want_stats ? a->stat_partials : nullptr;
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("OCT_FIRST_MFMA"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
+  if (use_mfma && (d->w % 32) == 0 && d->cout >= 32 && (size_t)d->n * d->h * d->w < (1ull << 31)) {
+    // matrix-pipe kernel: a wave per 32 consecutive pixels of a row
+#define LAUNCHM(F, KD) hipLaunchKernelGGL((first_fprop_mfma_kernel<F, KD>), dim3(grid), dim3(256), 0, s, (const bf16_t*)a->x0, \
+                                          (const bf16_t*)a->wpacked, (bf16_t*)a->y0, st, d->n, d->h, d->w, d->depth)
+    if (d->depth > 0) { if (d->cout == 32) LAUNCHM(32, 3); else LAUNCHM(64, 3); }
+    else { if (d->cout == 32) LAUNCHM(32, 1); else LAUNCHM(64, 1); }
+#undef LAUNCHM
+    int rcm = oct_check_launch("first_fprop_mfma");
+    return rcm ? rcm : 1;
+  }
   if (d->depth > 0) {
     if ((size_t)d->n * d->h * d->w >= (1ull << 32)) return 0;   // 32-bit voxel arithmetic
 #define LAUNCH3(F) hipLaunchKernelGGL(first_fprop3d_kernel<F>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a->x0, \
