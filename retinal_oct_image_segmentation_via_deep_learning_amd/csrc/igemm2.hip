@@ -73,6 +73,16 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   constexpr int NSLOT = (NPIX + 63) / 64;       // producers (4 waves): 64 pixels x 4 channel groups per pass
   constexpr int NT = WN * NF * 32;
   constexpr int KSTEPS = TAPS * 2;              // k16 steps per 32-channel chunk
+#ifndef IG2_M16
+#define IG2_M16 1
+#endif
+  // M16: the streamed-weight 3x3 kernels multiply with v_mfma_f32_16x16x32_bf16 -- 18 half-steps (tap, 16-pixel half) of
+  // MF * 2NF MFMAs per stage instead of 18 k16 steps of MF * NF.  Same FLOPs per cycle, same LDS and weight bytes, same
+  // packed-weight layout (a lane gathers its 16 B from the 32x32x16 fragment order); an accumulator acc[m][q] holds four
+  // 16x16 blocks, register 4*S + e of quarter S = 2*half + cc = channel 16*cc + 4*(lane>>4) + e at pixel 16*half + (lane&15).
+  // Why: these kernels are power-bound and the chip holds a higher clock on this shape -- a timing-only
+  // build that issued the same FLOPs as 16x16x32 measured -9 % on fprop / dgrad of the Cout >= 128 layers.
+  constexpr bool M16 = IG2_M16 && TAPS == 9 && !WRES && !D3 && NF == 2;   // NF == 1 (deferred epilogue riding on the half-steps) measured 5-12 % slower with it
   typedef Mma<bf16_t> M;
   typedef M::Frag Frag;
 
@@ -325,7 +335,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 
   constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? 3 : ((MF * NF >= 4) ? 6 : 9));
   static_assert(KSTEPS % PF == 0, "ring slots must line up across stages");
-  Frag wring[WRES ? 1 : PF][NF];
+  Frag wring[(WRES || M16) ? 1 : PF][NF];
+  // M16: weights of two taps.  Tap t sits in slot t & 1 and tap t + 1 is fetched while it multiplies; a stage has nine taps,
+  // so the next stage's tap 0 lands in slot 1 and is moved to slot 0 when that stage starts (16 v_mov per stage; a third
+  // slot instead cost 16 more registers and spilled the 128-channel kernels)
+  Frag a16[M16 ? 2 : 1][M16 ? 2 * NF : 1];
   f32x16 acc[MF][NF];
   float s1[STATS ? NF : 1][16], s2[STATS ? NF : 1][16];  // BN partial sums (lane = pixel column)
   if (STATS) {
@@ -397,7 +411,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const u32x2 v = {pk[2 * g], pk[2 * g + 1]};
-      *reinterpret_cast<u32x2*>(sc + r * 80 + (8 * g + 4 * hh) * 2) = v;   // pixel r, channels 8g+4hh..+3
+      if (M16)   // quarter g = 2*half + cc: pixel 16*half + (lane&15), channels 16*cc + 4*(lane>>4) ..+3
+        *reinterpret_cast<u32x2*>(sc + (16 * (g >> 1) + (lane & 15)) * 80 + (16 * (g & 1) + 4 * (lane >> 4)) * 2) = v;
+      else
+        *reinterpret_cast<u32x2*>(sc + r * 80 + (8 * g + 4 * hh) * 2) = v;   // pixel r, channels 8g+4hh..+3
     }
   };
   auto frag_from_lds = [&](u32x4 (&tv)[2], int slot = 0) {
@@ -543,7 +560,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         if (n_item >= nitems_wg) { n_item = item; n_ch = ch; }  // last stage: harmless re-read of valid memory
         const int n_nbi = n_item == item ? nbi : (nbi + 1 == p.nblk ? 0 : nbi + 1);
         wbase_n = p.wp + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512 + lane * 8;
-        if (sidx == 0) {
+        if (sidx == 0 && !M16) {
 #pragma unroll
           for (int j = 0; j < PF; ++j)
 #pragma unroll
@@ -558,6 +575,57 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
         return ((m + ty) * LW + tx) * PIXB + k16 * 32;
       };
+      if constexpr (M16) {
+        const int r16 = lane & 15, kg = lane >> 4;
+        const unsigned char* lb16 = tb + ((wm * MF) * LW + r16) * PIXB + kg * 16;
+        auto boff = [](int u, int m) constexpr { const int t = u >> 1; return ((m + t / 3) * LW + t % 3 + 16 * (u & 1)) * PIXB; };
+        // this lane's 16 B of a weight fragment pair: rows 16*cc + r16 of k16 fragment kg>>1, k half kg&1 (32x32x16 order)
+        const int lpart = (kg >> 1) * 512 + ((kg & 1) * 32 + r16) * 8 - lane * 8;   // wbase / wbase_n carry lane*8
+        auto aoff = [&](int c) { return (size_t)(c >> 1) * qstride + (c & 1) * 128 + lpart; };
+        if (sidx == 0) {
+#pragma unroll
+          for (int c = 0; c < 2 * NF; ++c) a16[0][c] = M::load(wbase + aoff(c));
+        } else {
+#pragma unroll
+          for (int c = 0; c < 2 * NF; ++c) a16[0][c] = a16[1][c];   // fetched under the previous stage's last tap
+        }
+        Frag b16[2][MF];
+#pragma unroll
+        for (int m = 0; m < MF; ++m) b16[0][m] = M::load(lb16 + boff(0, m));
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {   // half-step s = 2*tap + pixel half
+          const int t = s >> 1;
+          if (s + 1 < KSTEPS) {
+#pragma unroll
+            for (int m = 0; m < MF; ++m) b16[(s + 1) & 1][m] = M::load(lb16 + boff(s + 1, m));
+          }
+#ifndef ABL_NO_WLOAD
+          if ((s & 1) == 0) {   // weights of tap t + 1 (the next stage's tap 0 under this one's last)
+            const int t2 = t + 1;
+            const bf16_t* wb = t2 < TAPS ? wbase : wbase_n;
+            const int tt = t2 < TAPS ? t2 : 0;
+#pragma unroll
+            for (int c = 0; c < 2 * NF; ++c) a16[t2 & 1][c] = M::load(wb + aoff(c) + tt * tstride);
+          }
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int c = 0; c < 2 * NF; ++c) {
+              if (s & 1) { if (c & 1) M::template mma16<3>(acc[m][c >> 1], a16[t & 1][c], b16[s & 1][m]); else M::template mma16<2>(acc[m][c >> 1], a16[t & 1][c], b16[s & 1][m]); }
+              else { if (c & 1) M::template mma16<1>(acc[m][c >> 1], a16[t & 1][c], b16[s & 1][m]); else M::template mma16<0>(acc[m][c >> 1], a16[t & 1][c], b16[s & 1][m]); }
+            }
+          if (DEFER && s >= 1 && (s - 1) % ESTRIDE == 0 && (s - 1) / ESTRIDE < NFR) {
+            if (pend) store_frag(((s - 1) / ESTRIDE) / NF, ((s - 1) / ESTRIDE) % NF);
+          }
+        }
+        if (DEFER && pend) {
+#pragma unroll
+          for (int idx = EHANDLED; idx < NFR; ++idx) store_frag(idx / NF, idx % NF);
+          pend = false;
+        }
+      } else {
       // ring of LD+1 fragment sets: the reads of step s+LD are in flight while step s multiplies
 #ifndef IG2_LD8
 #define IG2_LD8 1
@@ -599,6 +667,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         for (int idx = EHANDLED; idx < NFR; ++idx) store_frag(idx / NF, idx % NF);
         pend = false;
       }
+      }   // !M16
     }
 
     if (wave == 0) TRACE(1, sidx);
@@ -609,13 +678,17 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         // ragged last tile: pixels outside the image must not reach the BatchNorm sums (their stores are
         // skipped anyway).  Zeroed in place, inside this wave-uniform branch: no register cost on whole tiles.
         const bool col_in = (txi * TW + r) < p.w;   // lane = pixel column
+        const bool col_in0 = (txi * TW + (lane & 15)) < p.w, col_in1 = (txi * TW + 16 + (lane & 15)) < p.w;   // M16: per pixel half
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
-          const bool in = col_in && (tyi * TH + wm * MF + m) < p.h;
+          const bool rin = (tyi * TH + wm * MF + m) < p.h;
 #pragma unroll
           for (int q = 0; q < NF; ++q)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][q][i] = in ? acc[m][q][i] : 0.f;
+            for (int i = 0; i < 16; ++i) {
+              const bool in = rin && (M16 ? (i < 8 ? col_in0 : col_in1) : col_in);
+              acc[m][q][i] = in ? acc[m][q][i] : 0.f;
+            }
         }
       }
       if (!DEFER) set_item(img, tyi, txi, nbi);
@@ -675,6 +748,20 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         float* ws = wg_stats + parity * (WM * 2 * NT);
 #pragma unroll
         for (int q = 0; q < NF; ++q) {
+          if constexpr (M16) {
+            // registers 4*(2*half + cc) + e: both pixel halves carry the same channels 16*cc + 4*(lane>>4) + e
+            float v1[8], v2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v1[k] = s1[q][k] + s1[q][8 + k]; v2[k] = s2[q][k] + s2[q][8 + k]; }
+            const float t1 = reduce16_scatter8(v1, lane);
+            const float t2 = reduce16_scatter8(v2, lane);
+            if ((lane & 1) == 0) {
+              const int reg = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+              const int cl = (wn * NF + q) * 32 + 16 * (reg >> 2) + 4 * (lane >> 4) + (reg & 3);
+              ws[(wm * 2 + 0) * NT + cl] = t1;
+              ws[(wm * 2 + 1) * NT + cl] = t2;
+            }
+          } else {
           const float t1 = reduce32_scatter16(s1[q], lane);
           const float t2 = reduce32_scatter16(s2[q], lane);
           if ((lane & 1) == 0) {
@@ -682,6 +769,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
             const int cl = (wn * NF + q) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
             ws[(wm * 2 + 0) * NT + cl] = t1;
             ws[(wm * 2 + 1) * NT + cl] = t2;
+          }
           }
 #pragma unroll
           for (int i = 0; i < 16; ++i) { s1[q][i] = 0.f; s2[q][i] = 0.f; }

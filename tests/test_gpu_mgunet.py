@@ -157,7 +157,7 @@ def test_bilinear_resize_matches_torch_both_ways(dtype, tol, shape, size):
     xr = x.to(tdt).double().permute(0, 3, 1, 2).requires_grad_(True)
     ref = F.interpolate(xr, size=size, mode="bilinear", align_corners=True)
     (ref * r.double().permute(0, 3, 1, 2)).sum().backward()
-    assert float((out.float().cpu().double() - ref.detach().permute(0, 2, 3, 1)).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert float((out.detach().float().cpu().double() - ref.detach().permute(0, 2, 3, 1)).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
     gref = xr.grad.permute(0, 2, 3, 1)
     assert float((xd.grad.float().cpu().double() - gref).abs().max()) <= tol * max(1.0, float(gref.abs().max())) * 4
 
