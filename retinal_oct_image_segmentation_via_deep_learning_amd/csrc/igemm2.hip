@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // 16x16 blocks, register 4*S + e of quarter S = 2*half + cc = channel 16*cc + 4*(lane>>4) + e at pixel 16*half + (lane&15).
   // Why: these kernels are power-bound and the chip holds a higher clock on this shape -- a timing-only
   // build that issued the same FLOPs as 16x16x32 measured -9 % on fprop / dgrad of the Cout >= 128 layers.
-  constexpr bool M16 = IG2_M16 && TAPS == 9 && !WRES && !D3 && NF == 2;   // NF == 1 (deferred epilogue riding on the half-steps) measured 5-12 % slower with it
+  constexpr bool M16 = IG2_M16 && TAPS == 9 && !WRES && NF == 2;   // NF == 1 (deferred epilogue riding on the half-steps) measured 5-12 % slower with it
   typedef Mma<bf16_t> M;
   typedef M::Frag Frag;
 
