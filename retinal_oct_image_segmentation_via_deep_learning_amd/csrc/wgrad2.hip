@@ -278,8 +278,18 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   const int pair = MULTI ? 0 : wave % PAIRS, psx = MULTI ? 0 : wave / PAIRS;
   const int cb = MULTI ? (wave >> 1) * WCB : pair / IB, ib = MULTI ? (wave & 1) * WIB : pair % IB;   // MULTI: first pair of the wave's sub-block
   const int g4 = lane >> 4, li = lane & 15;
+#ifndef W2_M16
+#define W2_M16 1
+#endif
+  // W16 (3x3 kernels): v_mfma_f32_16x16x32_bf16 -- a fragment is 32 pixels (a whole tile row) x 16 channels, D = 16 co x 16 ci
+  // in quarter S = 2*(co half) + (ci half) of the tap's accumulator: register 4S + e = (co 16a + 4*(lane>>4) + e, ci 16b + (lane&15)).
+  // Same FLOPs, LDS reads and loop as the 32x32x16 form (pixel halves become channel halves); the chip holds a higher clock
+  // on this shape (igemm2.hip, M16).
+  constexpr bool W16 = W2_M16 && TAPS == 9;
   // transposed-read lane address inside a [pixel][64 B] block: pixel 8*(g4>>1) + (li>>2), channel 16*(g4&1) + 4*(li&3)
-  const int lane_off = (8 * (g4 >> 1) + (li >> 2)) * 64 + (16 * (g4 & 1) + 4 * (li & 3)) * 2;
+  // (W16: pixel 8*g4 + (li>>2), channel 4*(li&3) of the 16-channel half)
+  const int lane_off = W16 ? (8 * g4 + (li >> 2)) * 64 + (4 * (li & 3)) * 2
+                           : (8 * (g4 >> 1) + (li >> 2)) * 64 + (16 * (g4 & 1) + 4 * (li & 3)) * 2;
 
   constexpr int NACC = MULTI ? WCB * WIB : TAPS;
   f32x16 acc[NACC];
@@ -320,7 +330,12 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       // four-slot register window.  0.44 transposed reads per MFMA instead of 1.11: with one read per MFMA
       // the four waves asked the LDS for 142 B/clk, more than the 128 B/clk it delivers.
       constexpr int NI = ROWS + 2, NB = NI * 6;
-      auto bo = [&](int j) { return ((psx * ROWS + j / 6) * LW + ((j / 3) & 1) * 16 + j % 3) * 64; };
+      // j = (input row, half, tx): half = 16-pixel half of the row, or (W16) 16-channel half of the 32-pixel fragment
+      auto bo = [&](int j) {
+        return W16 ? ((psx * ROWS + j / 6) * LW + j % 3) * 64 + ((j / 3) & 1) * 32
+                   : ((psx * ROWS + j / 6) * LW + ((j / 3) & 1) * 16 + j % 3) * 64;
+      };
+      auto ao = [&](int k) { return W16 ? ((psx * ROWS + (k >> 1)) * TW) * 64 + (k & 1) * 32 : a_off(k); };
       // input fragments run LA iterations (up to 3 MFMAs = 96 matrix cycles each) ahead of their use.  LA = 2 left the
       // reads ~190 cycles of lead, about one loaded-LDS round trip; W2_LA (default 4) doubles it for 8 VGPRs.
 #ifndef W2_LA
@@ -329,8 +344,8 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       constexpr int LA = W2_LA;
       bf16x8 aw[4][2];
       bf16x8 bq[LA + 1];
-      aw[0][0] = tr_frag(dy_t + a_off(0));
-      aw[0][1] = tr_frag(dy_t + a_off(1));
+      aw[0][0] = tr_frag(dy_t + ao(0));
+      aw[0][1] = tr_frag(dy_t + ao(1));
 #pragma unroll
       for (int j = 0; j < LA; ++j) bq[j] = tr_frag(in_t + bo(j));
 #pragma unroll
@@ -340,16 +355,22 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
           const int j = i * 6 + hx, h = hx / 3, tx = hx % 3;
           if (j + LA < NB) bq[(j + LA) % (LA + 1)] = tr_frag(in_t + bo(j + LA));
           if (hx == 0 && i + 1 < ROWS) {   // dY of the next output row, a whole input row ahead of its first use
-            aw[(i + 1) & 3][0] = tr_frag(dy_t + a_off(2 * (i + 1)));
-            aw[(i + 1) & 3][1] = tr_frag(dy_t + a_off(2 * (i + 1) + 1));
+            aw[(i + 1) & 3][0] = tr_frag(dy_t + ao(2 * (i + 1)));
+            aw[(i + 1) & 3][1] = tr_frag(dy_t + ao(2 * (i + 1) + 1));
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int ty = 0; ty < 3; ++ty) {
             const int k = i - ty;   // output row that sees input row i through tap row ty
             if (k < 0 || k >= ROWS) continue;
+            if constexpr (W16) {   // h = ci half of the input fragment; both co halves of the dY row multiply it
+              if (do_bias && ty == 0 && tx == 0 && h == 0) { M::template mma16<0>(accb, aw[k & 3][0], ones); M::template mma16<2>(accb, aw[k & 3][1], ones); }
+              if (h == 0) { M::template mma16<0>(acc[ty * 3 + tx], aw[k & 3][0], bq[j % (LA + 1)]); M::template mma16<2>(acc[ty * 3 + tx], aw[k & 3][1], bq[j % (LA + 1)]); }
+              else { M::template mma16<1>(acc[ty * 3 + tx], aw[k & 3][0], bq[j % (LA + 1)]); M::template mma16<3>(acc[ty * 3 + tx], aw[k & 3][1], bq[j % (LA + 1)]); }
+            } else {
             if (do_bias && ty == 0 && tx == 0) M::mma(accb, aw[k & 3][h], ones);
             M::mma(acc[ty * 3 + tx], aw[k & 3][h], bq[j % (LA + 1)]);
+            }
           }
         }
     } else if constexpr (MULTI) {
@@ -428,19 +449,21 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       }
     }
   } else {
-  const int ci = ci_sb + ib * 32 + r;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int co = co_sb + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      // W16: register 4S + e, S = 2a + b -> (co 16a + 4*(lane>>4) + e, ci 16b + (lane&15))
+      const int co = co_sb + cb * 32 + (W16 ? 16 * (i >> 3) + 4 * g4 + (i & 3) : (i & 3) + 8 * (i >> 2) + 4 * hh);
+      const int ci = ci_sb + ib * 32 + (W16 ? 16 * ((i >> 2) & 1) + li : r);
       float* const q = &out[((size_t)t * p.cout + co) * p.ktot + ci];
       if (p.part_mode) *q = acc[t][i]; else atomicAdd(q, acc[t][i]);
     }
-  if (do_bias && r == 0) {
+  if (do_bias && (W16 ? li == 0 : r == 0)) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int co = co_sb + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (W16 && ((i >> 2) & 1)) continue;   // the bias sums sit in the b = 0 quarters
+      const int co = co_sb + cb * 32 + (W16 ? 16 * (i >> 3) + 4 * g4 + (i & 3) : (i & 3) + 8 * (i >> 2) + 4 * hh);
       if (p.part_mode) p.dbias_part[(size_t)slab * p.cout + co] = accb[i];
       else atomicAdd(&p.dbias[co % cr], accb[i]);
     }
