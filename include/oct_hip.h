@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCT_VERSION 200 /* 0.2.0: (kh,kw) kernels, depth taps, partials, ReLayNet / 3-D / per-class metric entry points */
+#define OCT_VERSION 210 /* 0.2.1: + oct_bilinear_resize_*, floor-mode max-pooling (MGU-Net); 0.2.0: (kh,kw) kernels, depth taps, partials, ReLayNet / 3-D / per-class metric entry points */
 
 /* dtypes of activation storage */
 #define OCT_DT_BF16 0
