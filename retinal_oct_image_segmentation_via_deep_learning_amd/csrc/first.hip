@@ -426,6 +426,152 @@ __global__ void __launch_bounds__(256) first_wgrad_kernel(const bf16_t* __restri
   }
 }
 
+// wgrad on the matrix pipe (2-D, W % 32 == 0): dW[co][T] = sum over pixels dY[px][co] * x[px + tap T] as
+// D[32 co][32 T] += A[co][16 px] * B[16 px][T]: per 32 pixels of a row a wave brings dY (with the fused BatchNorm-backward
+// apply, rounded to bf16 exactly as the unfused pass would store it) into a wave-private [pixel][64 B] LDS tile, reads it back
+// transposed (ds_read_b64_tr_b16, as wgrad2) and multiplies by the tap matrix -- lane T gathers the 8 consecutive input
+// pixels of its tap per k16 step (lanes T >= 9 and rows outside the image contribute zeros).  Replaces 72 FMAs and nine
+// bounds-checked loads per pixel and 8-channel group.
+typedef short f1_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 f1_tr_frag(const unsigned char* base_lo) {
+  typedef __attribute__((address_space(3))) f1_s16x4 lds_s16x4;
+  const f1_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base_lo));
+  const f1_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base_lo + 4 * 64));  // pixels +4
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) first_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                               float* __restrict__ dwp, int n, int h, int w,
+                                                               const bf16_t* __restrict__ yraw, const float* __restrict__ coef,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               int part_mode) {
+  constexpr int NB = F / 32, CPP = F / 8, NCH = (32 * CPP) / 64;   // 16-B chunks per pixel / per lane and tensor
+  typedef Mma<bf16_t> M;
+  __shared__ __attribute__((aligned(16))) unsigned char tile[4][NB][32 * 64];
+  __shared__ float sacc[4][9 * F];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int T = lane & 31, khalf = lane >> 5;
+  const int g4 = lane >> 4, li = lane & 15;
+  const int tr_off = (8 * (g4 >> 1) + (li >> 2)) * 64 + (16 * (g4 & 1) + 4 * (li & 3)) * 2;   // see wgrad2.hip
+  // this lane's chunks of the dY tile: chunk c = lane + 64k -> pixel c / CPP, 8-channel group c % CPP (the same for every k)
+  const int part = lane % CPP;
+  float k0[8], k1[8], k2[8], sc[8], sh[8];
+  if (coef) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      k0[j] = coef[part * 8 + j]; k1[j] = coef[F + part * 8 + j]; k2[j] = coef[2 * F + part * 8 + j];
+      sc[j] = scale[part * 8 + j]; sh[j] = shift[part * 8 + j];
+    }
+  }
+  const bf16_t* ysrc = coef ? yraw : dy;
+  // tap of this lane
+  const int tdy = T < 9 ? T / 3 - 1 : 0, tdx = T < 9 ? T % 3 - 1 : 0;
+  const int toff = tdy * w + tdx;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+
+  const unsigned npix = (unsigned)n * h * w;
+  const unsigned ngroups = npix >> 5, gstride = gridDim.x * 4;
+  u32x4 dn[NCH], yn[NCH];
+  unsigned short vn[16];
+  unsigned vmask = 0, e0 = 0, e31 = 0;
+  auto fetch = [&](unsigned g) {
+    const unsigned q0 = g << 5;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const unsigned c = lane + 64 * k;
+      const size_t off = ((size_t)q0 + c / CPP) * F + part * 8;
+      dn[k] = *reinterpret_cast<const u32x4*>(dy + off);
+      yn[k] = *reinterpret_cast<const u32x4*>(ysrc + off);
+    }
+    const unsigned row = q0 / (unsigned)w;
+    const int x0 = (int)(q0 - row * (unsigned)w), yy = (int)(row % (unsigned)h);
+    const bool ok = T < 9 && (tdy < 0 ? yy > 0 : (tdy > 0 ? yy + 1 < h : true));
+    vmask = ok ? 0xffffffffu : 0u;
+    // the only pixels of a 32-pixel row segment whose x neighbour can leave the image: the first (dx = -1) and the last (dx = +1)
+    e0 = (tdx < 0 && x0 == 0 && khalf == 0) ? 0xffff0000u : 0xffffffffu;          // element j = 0 of k16 step 0
+    e31 = (tdx > 0 && x0 + 32 == w && khalf == 1) ? 0x0000ffffu : 0xffffffffu;     // element j = 7 of k16 step 1
+    const long long base = (long long)q0 + 8 * khalf + (ok ? toff : 0);
+    const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      long long idx = base + 16 * (jj / 8) + (jj % 8);
+      if (jj == 0) idx = idx < 0 ? 0 : idx;                                   // x[-1] at the very first pixel
+      if (jj == 15) idx = idx > (long long)npix - 1 ? (long long)npix - 1 : idx;   // one past the last
+      vn[jj] = xs[idx];
+    }
+  };
+  unsigned g = blockIdx.x * 4 + wave;
+  fetch(g < ngroups ? g : 0u);
+  for (; g < ngroups; g += gstride) {
+    // ---- dY tile of this group into the wave's LDS tile ----
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      u32x4 d = dn[k];
+      if (coef) {
+        const u32x4 yq = yn[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float dv[2], yv[2];
+          dv[0] = __uint_as_float(d[e] << 16); dv[1] = __uint_as_float(d[e] & 0xffff0000u);
+          yv[0] = __uint_as_float(yq[e] << 16); yv[1] = __uint_as_float(yq[e] & 0xffff0000u);
+          float o[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int j = 2 * e + u;
+            const float gm = fmaf(yv[u], sc[j], sh[j]) > 0.f ? dv[u] : 0.f;
+            o[u] = fmaf(k0[j], gm, fmaf(k1[j], yv[u], k2[j]));   // rounded to bf16 by the pack: what the unfused pass stores
+          }
+          d[e] = f1_pack(o[0], o[1]);
+        }
+      }
+      const unsigned c = lane + 64 * k;
+      const int px = c / CPP;
+      *reinterpret_cast<u32x4*>(&tile[wave][part / 4][px * 64 + (part % 4) * 16]) = d;
+    }
+    // ---- tap matrix fragments ----
+    bf16x8 bfr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = ((unsigned)vn[8 * ks + 2 * e] | ((unsigned)vn[8 * ks + 2 * e + 1] << 16)) & vmask;
+      if (ks == 0) pk[0] &= e0; else pk[3] &= e31;
+      bfr[ks] = __builtin_bit_cast(bf16x8, pk);
+    }
+    fetch(g + gstride < ngroups ? g + gstride : g);   // next group's loads in flight under the MFMAs
+    asm volatile("" ::: "memory");                    // the transposed reads below must follow the tile writes above
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 afr = f1_tr_frag(&tile[wave][cb][0] + tr_off + ks * 16 * 64);
+        M::mma(acc[cb], afr, bfr[ks]);
+      }
+    asm volatile("" ::: "memory");
+  }
+  // D[row = co][col = T]: lane = tap T, registers = channels (i&3) + 8*(i>>2) + 4*khalf of the block
+  if (T < 9) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[wave][T * F + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * khalf] = acc[cb][i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * F; i += 256) {   // dwp[tap][co][ci = 0], waves summed in a fixed order
+    const float v = (sacc[0][i] + sacc[1][i]) + (sacc[2][i] + sacc[3][i]);
+    if (part_mode) dwp[(size_t)blockIdx.x * 9 * F + i] = v;
+    else atomicAdd(&dwp[i], v);
+  }
+}
+
 static bool f1_enabled() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("OCT_DISABLE_V2"); on = (e && e[0] == '1') ? 0 : 1; }
@@ -500,6 +646,17 @@ int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, 
   if (query) { *query = (int)b; return 1; }
   const int part_mode = d->partials ? 1 : 0;
   hipStream_t s = as_stream(stream);
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("OCT_FIRST_MFMA"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
+  if (use_mfma && d->depth == 0 && (d->w % 32) == 0 && d->cout >= 32) {
+#define LAUNCHM(F) hipLaunchKernelGGL(first_wgrad_mfma_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
+                                      (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
+                                      (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode)
+    if (d->cout == 32) LAUNCHM(32); else LAUNCHM(64);
+#undef LAUNCHM
+    int rcm = oct_check_launch("first_wgrad_mfma");
+    return rcm ? rcm : 1;
+  }
 #define LAUNCH(F) hipLaunchKernelGGL(first_wgrad_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
                                      (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
                                      (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode)
