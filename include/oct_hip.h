@@ -37,6 +37,7 @@ extern "C" {
 
 /* error codes */
 #define OCT_OK 0
+#define OCT_IMG_SHIFT_ALL 2  /* OctWgradDesc.in_img_shift: all depth taps in one launch */
 #define OCT_E_INVALID (-22)  /* bad descriptor / unsupported shape */
 #define OCT_E_LAUNCH (-5)    /* hipLaunch failure */
 #define OCT_E_NODEVICE (-19) /* no HIP device */
@@ -151,7 +152,8 @@ typedef struct OctWgradDesc {
   int kh, kw;        /* as in OctConvDesc; dwp is [kh*kw][cout][ktot] */
   int depth;         /* D > 0: volumes of D slices (see OctConvDesc).  One launch computes the weight gradient of ONE depth
                       * tap: the input tile is read from slice d + in_img_shift (zero outside the volume)              */
-  int in_img_shift;  /* -1, 0, +1 = kd - 1 (Conv3d); 0 otherwise                                                       */
+  int in_img_shift;  /* -1, 0, +1 = kd - 1 (Conv3d); 0 otherwise; OCT_IMG_SHIFT_ALL: every depth tap in one launch, dwp =
+                      * [3][taps][cout][cin] (only where oct_conv_wgrad_all_depth_taps_ok says so)                    */
   int dy_img_mul, dy_img_add; /* dy_mode S2D only, 0,0 = identity: dY is gathered from image img*mul + add
                       * (ConvTranspose3d weight gradient: two launches, mul = 2, add = kd)                               */
   int partials;      /* 0: partial sums of the workgroups meet in dwp through fp32 atomics (dwp zeroed by the caller; the
@@ -183,6 +185,9 @@ int oct_reduce_bias_partials(const float* part, int nparts, int rows, int channe
 /* 1 when oct_conv_wgrad accepts dy_coef (fused BatchNorm-backward apply) for this descriptor, else 0: the
  * caller then materialises dY with oct_bn_bwd_apply first.  Host-only query, never fails.               */
 int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d);
+/* 1 when oct_conv_wgrad accepts in_img_shift = OCT_IMG_SHIFT_ALL for this descriptor (nn.Conv3d(1, F, 3) weight gradient,
+ * engine3d: all 27 taps in one pass over dY instead of three), else 0.  Host-only query, never fails.    */
+int oct_conv_wgrad_all_depth_taps_ok(const OctWgradDesc* d);
 /* dwp -> torch-layout gradient.  mode: OCT_PACK_CONV_FPROP (grad[co][ci][tap]),
  * OCT_PACK_DECONV_FPROP (grad[ci][co][dydx]) or OCT_PACK_1X1_FPROP (grad[co][ci]).
  * accumulate != 0: grad += */

@@ -17,6 +17,7 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 DT_BF16, DT_F32 = 0, 1
 XF_NONE, XF_AFFINE_RELU, XF_AFFINE = 0, 1, 2
 IN_PLAIN, IN_S2D = 0, 1
+IMG_SHIFT_ALL = 2   # OctWgradDesc.in_img_shift: all depth taps in one launch (OCT_IMG_SHIFT_ALL)
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ACT_PRELU = 3   # host-side tag only: PReLU has its own entry points (oct_affine_prelu_fwd / _bwd)
 OUT_PLAIN, OUT_D2S = 0, 1
@@ -93,6 +94,7 @@ SIGNATURES = {
     "oct_conv_forward": (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvArgs), c_void_p]),
     "oct_conv_wgrad": (c_int, [C.POINTER(WgradDesc), C.POINTER(WgradArgs), c_void_p]),
     "oct_conv_wgrad_fused_apply_ok": (c_int, [C.POINTER(WgradDesc)]),
+    "oct_conv_wgrad_all_depth_taps_ok": (c_int, [C.POINTER(WgradDesc)]),
     "oct_conv_wgrad_partials": (c_int, [C.POINTER(WgradDesc)]),
     "oct_reduce_bias_partials": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "oct_unpack_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -442,16 +442,19 @@ __device__ __forceinline__ bf16x8 f1_tr_frag(const unsigned char* base_lo) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int F>
+// KD = 3: Conv3d(1 -> F, 3x3x3) -- all 27 taps T = kd*9 + kh*3 + kw in ONE launch (dwp[T][co] = the [3][9][cout] slab of the
+// three per-depth-tap launches of the stencil kernel, which read dY three times)
+template <int F, int KD>
 __global__ void __launch_bounds__(256) first_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                float* __restrict__ dwp, int n, int h, int w,
                                                                const bf16_t* __restrict__ yraw, const float* __restrict__ coef,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               int part_mode) {
+                                                               int part_mode, int depth) {
+  constexpr int NTAP = 9 * KD;
   constexpr int NB = F / 32, CPP = F / 8, NCH = (32 * CPP) / 64;   // 16-B chunks per pixel / per lane and tensor
   typedef Mma<bf16_t> M;
   __shared__ __attribute__((aligned(16))) unsigned char tile[4][NB][32 * 64];
-  __shared__ float sacc[4][9 * F];
+  __shared__ float sacc[4][NTAP * F];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int T = lane & 31, khalf = lane >> 5;
@@ -469,8 +472,9 @@ __global__ void __launch_bounds__(256) first_wgrad_mfma_kernel(const bf16_t* __r
   }
   const bf16_t* ysrc = coef ? yraw : dy;
   // tap of this lane
-  const int tdy = T < 9 ? T / 3 - 1 : 0, tdx = T < 9 ? T % 3 - 1 : 0;
-  const int toff = tdy * w + tdx;
+  const int t9 = T % 9;
+  const int tdz = (KD == 3 && T < NTAP) ? T / 9 - 1 : 0, tdy = T < NTAP ? t9 / 3 - 1 : 0, tdx = T < NTAP ? t9 % 3 - 1 : 0;
+  const int toff = tdz * h * w + tdy * w + tdx;
   f32x16 acc[NB];
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb)
@@ -493,7 +497,9 @@ __global__ void __launch_bounds__(256) first_wgrad_mfma_kernel(const bf16_t* __r
     }
     const unsigned row = q0 / (unsigned)w;
     const int x0 = (int)(q0 - row * (unsigned)w), yy = (int)(row % (unsigned)h);
-    const bool ok = T < 9 && (tdy < 0 ? yy > 0 : (tdy > 0 ? yy + 1 < h : true));
+    const int zz = KD == 3 ? (int)((row / (unsigned)h) % (unsigned)depth) : 0;
+    const bool ok = T < NTAP && (tdy < 0 ? yy > 0 : (tdy > 0 ? yy + 1 < h : true)) &&
+                    (tdz < 0 ? zz > 0 : (tdz > 0 ? zz + 1 < depth : true));
     vmask = ok ? 0xffffffffu : 0u;
     // the only pixels of a 32-pixel row segment whose x neighbour can leave the image: the first (dx = -1) and the last (dx = +1)
     e0 = (tdx < 0 && x0 == 0 && khalf == 0) ? 0xffff0000u : 0xffffffffu;          // element j = 0 of k16 step 0
@@ -558,16 +564,16 @@ __global__ void __launch_bounds__(256) first_wgrad_mfma_kernel(const bf16_t* __r
     asm volatile("" ::: "memory");
   }
   // D[row = co][col = T]: lane = tap T, registers = channels (i&3) + 8*(i>>2) + 4*khalf of the block
-  if (T < 9) {
+  if (T < NTAP) {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) sacc[wave][T * F + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * khalf] = acc[cb][i];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 9 * F; i += 256) {   // dwp[tap][co][ci = 0], waves summed in a fixed order
+  for (int i = threadIdx.x; i < NTAP * F; i += 256) {   // dwp[tap][co][ci = 0], waves summed in a fixed order
     const float v = (sacc[0][i] + sacc[1][i]) + (sacc[2][i] + sacc[3][i]);
-    if (part_mode) dwp[(size_t)blockIdx.x * 9 * F + i] = v;
+    if (part_mode) dwp[(size_t)blockIdx.x * NTAP * F + i] = v;
     else atomicAdd(&dwp[i], v);
   }
 }
@@ -635,6 +641,16 @@ extern "C" int oct_conv_wgrad_fused_apply_ok(const OctWgradDesc* d) {
   return (size_t)d->n * d->h * d->w < (1u << 31) ? 1 : 0;
 }
 
+// Host query: 1 when oct_conv_wgrad accepts in_img_shift = OCT_IMG_SHIFT_ALL for this descriptor (all three depth taps of a
+// Conv3d(1 -> F) weight gradient in one launch, dwp = [3][9][cout]); else the caller launches once per depth tap.
+extern "C" int oct_conv_wgrad_all_depth_taps_ok(const OctWgradDesc* d) {
+  if (!d || d->depth <= 0 || d->partials) return 0;
+  if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
+  const char* e = getenv("OCT_FIRST_MFMA");
+  if (e && e[0] == '0') return 0;
+  return ((d->w % 32) == 0 && d->cout >= 32 && (size_t)d->n * d->h * d->w < (1u << 31)) ? 1 : 0;
+}
+
 int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query) {
   if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
   if (!query && a->dbias) return 0;   // no bias-gradient path in the direct kernel: the MFMA kernels take it
@@ -648,15 +664,18 @@ int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, 
   hipStream_t s = as_stream(stream);
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("OCT_FIRST_MFMA"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
-  if (use_mfma && d->depth == 0 && (d->w % 32) == 0 && d->cout >= 32) {
-#define LAUNCHM(F) hipLaunchKernelGGL(first_wgrad_mfma_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
-                                      (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
-                                      (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode)
-    if (d->cout == 32) LAUNCHM(32); else LAUNCHM(64);
+  const bool all_taps = d->depth > 0 && d->in_img_shift == OCT_IMG_SHIFT_ALL;
+  if (use_mfma && (d->depth == 0 || all_taps) && (d->w % 32) == 0 && d->cout >= 32) {
+#define LAUNCHM(F, KD) hipLaunchKernelGGL((first_wgrad_mfma_kernel<F, KD>), dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
+                                          (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
+                                          (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode, d->depth)
+    if (all_taps) { if (d->cout == 32) LAUNCHM(32, 3); else LAUNCHM(64, 3); }
+    else { if (d->cout == 32) LAUNCHM(32, 1); else LAUNCHM(64, 1); }
 #undef LAUNCHM
     int rcm = oct_check_launch("first_wgrad_mfma");
     return rcm ? rcm : 1;
   }
+  if (all_taps) return 0;   // only the matrix-pipe kernel takes all depth taps at once (oct_conv_wgrad_all_depth_taps_ok)
 #define LAUNCH(F) hipLaunchKernelGGL(first_wgrad_kernel<F>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
                                      (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
                                      (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode)

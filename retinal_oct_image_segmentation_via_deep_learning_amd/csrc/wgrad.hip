@@ -212,7 +212,10 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
             d->taps, d->kh, d->kw);
   OCT_CHECK(kh != 7 || (d->dy_mode == OCT_IN_PLAIN && !a->dy_coef), "oct_conv_wgrad: 7x3 takes a plain dY");
   OCT_CHECK(d->depth >= 0 && (d->depth == 0 || ((d->n % d->depth) == 0 && kh != 7)), "oct_conv_wgrad: bad depth %d for n=%d", d->depth, d->n);
-  OCT_CHECK(d->in_img_shift >= -1 && d->in_img_shift <= 1 && (d->in_img_shift == 0 || d->depth > 0), "oct_conv_wgrad: in_img_shift needs depth > 0");
+  OCT_CHECK(((d->in_img_shift >= -1 && d->in_img_shift <= 1) || d->in_img_shift == OCT_IMG_SHIFT_ALL) && (d->in_img_shift == 0 || d->depth > 0),
+            "oct_conv_wgrad: in_img_shift needs depth > 0");
+  OCT_CHECK(d->in_img_shift != OCT_IMG_SHIFT_ALL || oct_conv_wgrad_all_depth_taps_ok(d),
+            "oct_conv_wgrad: OCT_IMG_SHIFT_ALL is not available for this descriptor (oct_conv_wgrad_all_depth_taps_ok)");
   OCT_CHECK(d->dy_img_mul == 0 || d->dy_mode == OCT_IN_S2D, "oct_conv_wgrad: the dY image map belongs to S2D");
   OCT_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->c0 > 0 && d->c1 >= 0 && d->cout > 0, "oct_conv_wgrad: bad shape");
   OCT_CHECK(a->x0 && a->dy && a->dwp, "oct_conv_wgrad: null tensor");

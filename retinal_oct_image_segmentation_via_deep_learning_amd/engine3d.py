@@ -165,8 +165,13 @@ class UNet3DEngine(UNetEngine):
         src = rec.src
         cin = src.channels
         slab = self._dwp_take(27 * rec.cout * cin, dy.device).view(3, 9, rec.cout, cin)
-        for kdi in range(3):
-            self._wgrad(src, dy, rec.cout, 9, n, h, w, depth=depth, in_shift=kdi - 1, dwp=slab[kdi])
+        qd = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, rec.cout, 9, 0, 0, L.IN_PLAIN, 0, 0, depth, L.IMG_SHIFT_ALL, 0, 0, 0)
+        if src.bn0 is None and src.c1 == 0 and not self.deterministic and L.lib().oct_conv_wgrad_all_depth_taps_ok(C.byref(qd)):
+            # first layer (Cin = 1): the matrix-pipe kernel takes all 27 taps in one pass over dY
+            self._wgrad(src, dy, rec.cout, 9, n, h, w, depth=depth, in_shift=L.IMG_SHIFT_ALL, dwp=slab)
+        else:
+            for kdi in range(3):
+                self._wgrad(src, dy, rec.cout, 9, n, h, w, depth=depth, in_shift=kdi - 1, dwp=slab[kdi])
         L.check(L.lib().oct_unpack_wgrad3d(L.PACK_CONV3D_FPROP, slab.data_ptr(), G[rec.wkey].data_ptr(), rec.cout, cin, 0,
                                            int(accumulate), _stream()), "oct_unpack_wgrad3d")
         if not need_dx:

@@ -87,6 +87,15 @@ def test_conv3d_fprop_dgrad_wgrad_exact(env, dt, shape):
                                        torch.cuda.current_stream().cuda_stream))
     dw = torch.nn.grad.conv3d_weight(x, (cout, cin, 3, 3, 3), dy, padding=1)
     assert torch.equal(grad.double().cpu(), dw), "Conv3d wgrad"
+    # first layer on the matrix pipe: all 27 taps in ONE launch (OCT_IMG_SHIFT_ALL) must give the same slab
+    import ctypes as C
+    qd = L.WgradDesc(eng.dt, n, h, w, c0, c1, cout, 9, 0, 0, L.IN_PLAIN, 0, 0, d, L.IMG_SHIFT_ALL, 0, 0, 0)
+    ok = L.lib().oct_conv_wgrad_all_depth_taps_ok(C.byref(qd))
+    assert ok == (1 if (dt == "bf16" and cin == 1 and w % 32 == 0 and cout >= 32) else 0)
+    if ok:
+        slab1 = torch.zeros((3, 9, cout, cin), dtype=torch.float32, device="cuda")
+        eng._wgrad(src, dyd, cout, 9, n, h, w, depth=d, in_shift=L.IMG_SHIFT_ALL, dwp=slab1)
+        assert torch.equal(slab1, slab), "Conv3d(1 -> F) wgrad, all depth taps in one launch"
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
