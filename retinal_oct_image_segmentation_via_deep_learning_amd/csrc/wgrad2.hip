@@ -555,8 +555,8 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
     static int pairs2 = -1;
     if (pairs2 < 0) { const char* e = getenv("OCT_W2_PAIRS2"); pairs2 = (e && e[0] == '0') ? 0 : 1; }
     if (big) launch_w2<9, 2, 2, 8>(p, nco, nci, s);
-    else if (pairs2 && nci % 2 == 0 && (d->h % 8) == 0 && d->depth == 0 && d->dy_img_mul == 0) launch_w2<9, 1, 2, 8>(p, nco, nci, s);
-    else if (pairs2 && nco % 2 == 0 && (d->h % 8) == 0 && d->depth == 0 && d->dy_img_mul == 0) launch_w2<9, 2, 1, 8>(p, nco, nci, s);
+    else if (pairs2 && nci % 2 == 0 && (d->h % 8) == 0 && d->dy_img_mul == 0) launch_w2<9, 1, 2, 8>(p, nco, nci, s);
+    else if (pairs2 && nco % 2 == 0 && (d->h % 8) == 0 && d->dy_img_mul == 0) launch_w2<9, 2, 1, 8>(p, nco, nci, s);
     else launch_w2<9, 1, 1, 16>(p, nco, nci, s);
   } else {
     static int multi = -1;

@@ -44,7 +44,8 @@ def pow2(g, shape, density=0.5):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 4, 8, 32, 16, 0, 32), (1, 6, 10, 20, 1, 0, 8), (1, 4, 8, 32, 8, 8, 16), (2, 2, 8, 32, 32, 32, 64),
                                    (2, 4, 16, 64, 1, 0, 32), (1, 3, 8, 24, 1, 0, 16),      # first layer: direct 27-tap kernels (bf16)
-                                   (1, 4, 16, 32, 64, 0, 128), (2, 2, 16, 64, 32, 0, 32)])  # pipelined kernels, whole tiles
+                                   (1, 4, 16, 32, 64, 0, 128), (2, 2, 16, 64, 32, 0, 32),   # pipelined kernels, whole tiles
+                                   (1, 2, 16, 32, 32, 32, 32), (1, 2, 16, 32, 32, 0, 64)])  # 32x64 / 64x32 weight-gradient blocks
 def test_conv3d_fprop_dgrad_wgrad_exact(env, dt, shape):
     """Conv3d 3x3x3 through the depth-tap GEMM (fprop + stats, dgrad with concat split, three-launch wgrad):
     integer activations, power-of-two weights -> every sum exact -> bit equality with torch's float64 conv3d."""
