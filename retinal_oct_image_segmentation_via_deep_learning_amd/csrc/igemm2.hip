@@ -82,7 +82,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // 16x16 blocks, register 4*S + e of quarter S = 2*half + cc = channel 16*cc + 4*(lane>>4) + e at pixel 16*half + (lane&15).
   // Why: these kernels are power-bound and the chip holds a higher clock on this shape -- a timing-only
   // build that issued the same FLOPs as 16x16x32 measured -9 % on fprop / dgrad of the Cout >= 128 layers.
-  constexpr bool M16 = IG2_M16 && TAPS == 9 && !WRES && NF == 2;   // NF == 1 (deferred epilogue riding on the half-steps) measured 5-12 % slower with it
+#ifndef IG2_M16_NF1
+#define IG2_M16_NF1 0
+#endif
+  constexpr bool M16 = IG2_M16 && TAPS == 9 && !WRES && (NF == 2 || IG2_M16_NF1);   // NF == 1: 5-12 % slower with the deferred epilogue riding on the half-steps,
+                                                                                    // +0.06 ms per step with the un-deferred one (-DIG2_M16_NF1=1): stays on 32x32x16
   typedef Mma<bf16_t> M;
   typedef M::Frag Frag;
 
@@ -371,7 +375,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // the LDS transpose + global stores of those fragments are interleaved with the MFMA steps of the
   // NEXT stage (a fragment every ESTRIDE steps), where they ride in the issue slots the matrix pipe
   // leaves free.  Done back to back they cost 3.5-5.8k cycles per item with the pipe idle.
-  constexpr bool DEFER = !WRES && NF == 1;   // register budget: 8 VGPRs per deferred fragment
+  constexpr bool DEFER = !WRES && NF == 1 && !M16;   // register budget: 8 VGPRs per deferred fragment (M16: the MFMAs leave half the issue slots of the 32x32x16 form)
   constexpr int NFR = MF * NF;
   constexpr int ESTRIDE = (KSTEPS - 2) / NFR > 0 ? (KSTEPS - 2) / NFR : 1;
   constexpr int EHANDLED = ((KSTEPS - 1 + ESTRIDE - 1) / ESTRIDE) < NFR ? ((KSTEPS - 1 + ESTRIDE - 1) / ESTRIDE) : NFR;
