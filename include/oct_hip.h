@@ -242,6 +242,14 @@ int oct_dact_bn_reduce(int dtype, const void* da, const void* dpool, const void*
                        const float* invstd, void* g, float* partials, int n, int h, int w, int c,
                        void* stream);
 int oct_dact_bn_reduce_blocks(int n, int h, int w, int c, int has_pool);
+/* Pooled layers (nn.MaxPool2d(2, 2) behind conv + BN + ReLU, YNet_2022.py:516-522) without a stored masked gradient: when
+ * oct_bn_bwd_apply_pool_ok(...) == 1, oct_dact_bn_reduce(da, dpool, ..., g = NULL) is the reduce-only pass and
+ * oct_bn_bwd_apply_pool re-derives g (pool routing to the first maximum + ReLU mask, rounded to the activation dtype) and
+ * writes dy = coef0*g + coef1*y + coef2 -- bit-identical to reduce(g) + oct_bn_bwd_apply(g), 11 instead of 12.5 bytes per
+ * element.  da may be NULL (no skip gradient); dy may alias da.                                              */
+int oct_bn_bwd_apply_pool_ok(int dtype, int n, int h, int w, int c);
+int oct_bn_bwd_apply_pool(int dtype, const void* da, const void* dpool, const void* y, const float* scale,
+                          const float* shift, const float* coef, void* dy, int n, int h, int w, int c, void* stream);
 /* partials -> dgamma, dbeta and the three coefficients of dy = k[0]*g + k[1]*y + k[2]        */
 int oct_bn_bwd_finalize(const float* partials, int nblocks, int c, double count,
                         const float* gamma, const float* mean, const float* invstd,

@@ -109,6 +109,9 @@ SIGNATURES = {
     "oct_dact_bn_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_dact_bn_reduce_blocks": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "oct_bn_bwd_apply_pool_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "oct_bn_bwd_apply_pool": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int, c_int, c_int, c_int, c_void_p]),
     "oct_bn_bwd_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int, c_void_p]),
     "oct_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,

@@ -302,11 +302,16 @@ __global__ void dact_bn_reduce_kernel(const T* da, const T* __restrict__ dpool, 
 // group) handles the two rows of its 2x2 window; the horizontal neighbour's activations come from
 // lane ^ G by shuffle, so every global access of a wave is one contiguous run (the window-per-thread
 // mapping above reads every other pixel per instruction and measured 1.6 TB/s).
-template <typename T>
+// APPLY = false: the reduction pass; g_out may be NULL (reduce only: the masked gradient is not written -- the apply pass
+// below re-derives it).  APPLY = true (`coef` = k[3][c]): the same routing and mask, then dy = k0*g + k1*y + k2 with g rounded
+// to the activation dtype first, i.e. bit for bit what bn_bwd_apply computes from a stored g -- but the stored g (2 B written,
+// 2 B read back per element) never exists: 11 instead of 12.5 bytes per element for the pooled layers.
+template <typename T, bool APPLY = false>
 __global__ void dact_pool_coalesced_kernel(const T* da, const T* __restrict__ dpool, const T* __restrict__ y,
                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                           T* g_out, float* __restrict__ partials, int n, int h, int w, int c) {
+                                           T* g_out, float* __restrict__ partials, int n, int h, int w, int c,
+                                           const float* __restrict__ coef = nullptr) {
   constexpr int V = 8;
   const int G = c / V;  // power of two, <= 32: lane ^ G is the same wave's neighbour column
   float s1[V], s2[V];
@@ -318,7 +323,13 @@ __global__ void dact_pool_coalesced_kernel(const T* da, const T* __restrict__ dp
   const int g = start % G;
   float sc[V], sh[V], mu[V], is[V];
   load_vec<float, V>(scale + g * V, sc); load_vec<float, V>(shift + g * V, sh);
-  load_vec<float, V>(mean + g * V, mu); load_vec<float, V>(invstd + g * V, is);
+  if (APPLY) {   // mu / is carry k1 / k2, k0 its own registers
+    load_vec<float, V>(coef + c + g * V, mu); load_vec<float, V>(coef + 2 * c + g * V, is);
+  } else {
+    load_vec<float, V>(mean + g * V, mu); load_vec<float, V>(invstd + g * V, is);
+  }
+  float k0[V];
+  if (APPLY) load_vec<float, V>(coef + g * V, k0);
   // 32-bit index arithmetic (the host routes tensors of 2^31 items and more to the general kernel): the five
   // 64-bit divisions this loop head used to carry are ~500 instructions per 100 B of payload
   const unsigned gshift = 31 - __builtin_clz((unsigned)G);   // G is a power of two
@@ -352,14 +363,21 @@ __global__ void dact_pool_coalesced_kernel(const T* da, const T* __restrict__ dp
       g0[j] = z0 > 0.f ? e0 : 0.f;
       g1[j] = z1 > 0.f ? e1 : 0.f;
       const float r0 = to_f32(from_f32<T>(g0[j])), r1 = to_f32(from_f32<T>(g1[j]));
-      s1[j] += r0 + r1;
-      s2[j] = fmaf(r0, (y0[j] - mu[j]) * is[j], s2[j]);
-      s2[j] = fmaf(r1, (y1[j] - mu[j]) * is[j], s2[j]);
+      if (APPLY) {   // the arithmetic of bn_bwd_apply on the stored (rounded) g
+        g0[j] = fmaf(k0[j], r0, fmaf(mu[j], y0[j], is[j]));
+        g1[j] = fmaf(k0[j], r1, fmaf(mu[j], y1[j], is[j]));
+      } else {
+        s1[j] += r0 + r1;
+        s2[j] = fmaf(r0, (y0[j] - mu[j]) * is[j], s2[j]);
+        s2[j] = fmaf(r1, (y1[j] - mu[j]) * is[j], s2[j]);
+      }
     }
-    store_vec_nt<T, V>(g_out + p0 * c + g * V, g0);
-    store_vec_nt<T, V>(g_out + p1 * c + g * V, g1);
+    if (APPLY || g_out) {
+      store_vec_nt<T, V>(g_out + p0 * c + g * V, g0);
+      store_vec_nt<T, V>(g_out + p1 * c + g * V, g1);
+    }
   }
-  block_reduce_store<V>(s1, s2, g, G, c, partials, true, nullptr);
+  if (!APPLY) block_reduce_store<V>(s1, s2, g, G, c, partials, true, nullptr);
 }
 
 // Un-pooled layers with 8-channel groups that divide the workgroup: the NHWC tensor is a flat array of
@@ -409,6 +427,33 @@ __global__ void __launch_bounds__(EW_THREADS) dact_bn_reduce_flat_kernel(
   block_reduce_store<V>(s1, s2, gi, G, c, partials, true, nullptr);
 }
 
+static bool pool_coalesced_ok(int n, int h, int w, int c) {
+  return vec_width(c) == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0 && (size_t)n * (h / 2) * w * (c / 8) < (1u << 31);
+}
+// 1 when the pooled BatchNorm backward can run as reduce-only pass (oct_dact_bn_reduce with g = NULL) + oct_bn_bwd_apply_pool
+extern "C" int oct_bn_bwd_apply_pool_ok(int dtype, int n, int h, int w, int c) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("OCT_POOL_APPLY"); on = (e && e[0] == '0') ? 0 : 1; }
+  return (on && (dtype == OCT_DT_BF16 || dtype == OCT_DT_F32) && n > 0 && h > 1 && w > 1 && (h % 2) == 0 && (w % 2) == 0 &&
+          pool_coalesced_ok(n, h, w, c)) ? 1 : 0;
+}
+// dy = k0*g + k1*y + k2 with g = [relu(bn(y)) > 0] * (da + dpool routed to the first maximum of its 2x2 window) re-derived
+// on the fly (see dact_pool_coalesced_kernel<T, true>); dy may alias da.
+extern "C" int oct_bn_bwd_apply_pool(int dtype, const void* da, const void* dpool, const void* y, const float* scale,
+                                     const float* shift, const float* coef, void* dy, int n, int h, int w, int c, void* stream) {
+  OCT_CHECK(dpool && y && scale && shift && coef && dy, "oct_bn_bwd_apply_pool: null pointer");
+  OCT_CHECK(oct_bn_bwd_apply_pool_ok(dtype, n, h, w, c), "oct_bn_bwd_apply_pool: shape not eligible (oct_bn_bwd_apply_pool_ok)");
+  const int blocks = ew_blocks((size_t)n * (h / 2) * w, c / 8, 2048);
+  hipStream_t s = as_stream(stream);
+  if (dtype == OCT_DT_BF16)
+    hipLaunchKernelGGL((dact_pool_coalesced_kernel<bf16_t, true>), dim3(blocks), dim3(EW_THREADS), 0, s, (const bf16_t*)da,
+                       (const bf16_t*)dpool, (const bf16_t*)y, scale, shift, nullptr, nullptr, (bf16_t*)dy, nullptr, n, h, w, c, coef);
+  else
+    hipLaunchKernelGGL((dact_pool_coalesced_kernel<float, true>), dim3(blocks), dim3(EW_THREADS), 0, s, (const float*)da,
+                       (const float*)dpool, (const float*)y, scale, shift, nullptr, nullptr, (float*)dy, nullptr, n, h, w, c, coef);
+  return oct_check_launch("bn_bwd_apply_pool");
+}
+
 extern "C" int oct_dact_bn_reduce_blocks(int n, int h, int w, int c, int has_pool) {
   const int v = vec_width(c);
   if (has_pool && v == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0 && (size_t)n * (h / 2) * w * (c / 8) < (1u << 31))  // coalesced pooled kernel: item = (row pair, x)
@@ -421,7 +466,8 @@ extern "C" int oct_dact_bn_reduce(int dtype, const void* da, const void* dpool, 
                                   const float* shift, const float* mean, const float* invstd, void* g,
                                   float* partials, int n, int h, int w, int c, void* stream) {
   OCT_CHECK(y && scale && shift && mean && invstd && partials, "oct_dact_bn_reduce: null pointer");
-  OCT_CHECK(g || !dpool, "oct_dact_bn_reduce: the pooled variant must write g");
+  OCT_CHECK(g || !dpool || oct_bn_bwd_apply_pool_ok(dtype, n, h, w, c),
+            "oct_dact_bn_reduce: the pooled variant must write g (reduce-only needs oct_bn_bwd_apply_pool_ok)");
   OCT_CHECK(da || dpool, "oct_dact_bn_reduce: need da or dpool");
   OCT_CHECK(n > 0 && h > 0 && w > 0 && c > 0, "oct_dact_bn_reduce: bad shape");
   OCT_CHECK(!dpool || ((h % 2 == 0) && (w % 2 == 0)), "oct_dact_bn_reduce: pooled layer needs even h, w");

@@ -485,6 +485,8 @@ class UNetEngine:
         dev = rec.y.device
         pooled = dpool is not None
         g = da if da is not None else self._act(n, h, w, c, dev)
+        # pooled layers: reduce only as well when the library can re-derive the routed, masked gradient in the apply pass
+        pool_fused = pooled and partials is None and self.debug is None and bool(lib.oct_bn_bwd_apply_pool_ok(self.dt, n, h, w, c))
         if partials is not None:
             nblk = partials.shape[0]
         else:
@@ -493,7 +495,8 @@ class UNetEngine:
             # non-pooled layers: reduce only (no masked copy is written); the apply pass re-derives the mask
             L.check(lib.oct_dact_bn_reduce(self.dt, L.ptr(da), L.ptr(dpool), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
                                            rec.bn.shift.data_ptr(), rec.bn.mean.data_ptr(), rec.bn.invstd.data_ptr(),
-                                           g.data_ptr() if pooled else None, partials.data_ptr(), n, h, w, c, _stream()),
+                                           g.data_ptr() if (pooled and not pool_fused) else None, partials.data_ptr(),
+                                           n, h, w, c, _stream()),
                     "oct_dact_bn_reduce")
         coef = torch.empty((3, c), dtype=torch.float32, device=dev)
         L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, c, float(n * h * w), self._P[rec.gkey].data_ptr(),
@@ -504,6 +507,11 @@ class UNetEngine:
             self.debug["g:" + rec.wkey] = g.float().clone()
         if defer_apply and not pooled:
             return g, coef   # the consumer (first-layer wgrad) applies dy = k0*mask*dA + k1*y + k2 on load
+        if pool_fused:
+            L.check(lib.oct_bn_bwd_apply_pool(self.dt, L.ptr(da), dpool.data_ptr(), rec.y.data_ptr(), rec.bn.scale.data_ptr(),
+                                              rec.bn.shift.data_ptr(), coef.data_ptr(), g.data_ptr(), n, h, w, c, _stream()),
+                    "oct_bn_bwd_apply_pool")
+            return g
         L.check(lib.oct_bn_bwd_apply(self.dt, g.data_ptr(), rec.y.data_ptr(), coef.data_ptr(),
                                      None if pooled else rec.bn.scale.data_ptr(),
                                      None if pooled else rec.bn.shift.data_ptr(), n * h * w, c, _stream()),

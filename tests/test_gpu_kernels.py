@@ -419,3 +419,43 @@ def test_errors_are_reported_not_thrown(env):
     assert rc == -22 and "taps" in L.last_error()
     with pytest.raises(L.OctError):
         L.check(rc, "oct_conv_forward")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape,with_skip", [((2, 8, 16, 32), True), ((1, 6, 10, 64), True), ((3, 4, 8, 16), False), ((2, 16, 32, 256), True)])
+def test_pooled_bn_backward_without_stored_masked_gradient_is_bit_identical(env, dt, shape, with_skip):
+    """oct_dact_bn_reduce(g = NULL) + oct_bn_bwd_apply_pool against the two-pass form that stores the routed, masked gradient g
+    (oct_dact_bn_reduce(g) + oct_bn_bwd_apply(g)): equal partial sums, equal dY, bit for bit."""
+    L, E = env
+    lib = L.lib()
+    n, h, w, c = shape
+    eng = E.UNetEngine(1, 2, 4, dt)
+    tdt = eng.tdt
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + c)
+    y = torch.randn(n, h, w, c, generator=g).to(tdt).cuda()
+    da = torch.randn(n, h, w, c, generator=g).to(tdt).cuda() if with_skip else None
+    dpool = torch.randn(n, h // 2, w // 2, c, generator=g).to(tdt).cuda()
+    scale = (torch.rand(c, generator=g) + 0.5).cuda(); shift = (torch.randn(c, generator=g) * 0.3).cuda()
+    mean = (torch.randn(c, generator=g) * 0.1).cuda(); invstd = (torch.rand(c, generator=g) + 0.5).cuda()
+    coef = torch.randn(3, c, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.oct_bn_bwd_apply_pool_ok(eng.dt, n, h, w, c) == 1
+    nblk = lib.oct_dact_bn_reduce_blocks(n, h, w, c, 1)
+    # two-pass reference form
+    g1 = da.clone() if with_skip else torch.empty_like(y)
+    p1 = torch.full((nblk, 2, c), float("nan"), device="cuda")
+    L.check(lib.oct_dact_bn_reduce(eng.dt, L.ptr(g1 if with_skip else None), dpool.data_ptr(), y.data_ptr(), scale.data_ptr(),
+                                   shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g1.data_ptr(), p1.data_ptr(), n, h, w, c, st))
+    L.check(lib.oct_bn_bwd_apply(eng.dt, g1.data_ptr(), y.data_ptr(), coef.data_ptr(), None, None, n * h * w, c, st))
+    # reduce only + fused apply
+    g2 = da.clone() if with_skip else torch.empty_like(y)
+    p2 = torch.full((nblk, 2, c), float("nan"), device="cuda")
+    L.check(lib.oct_dact_bn_reduce(eng.dt, L.ptr(g2 if with_skip else None), dpool.data_ptr(), y.data_ptr(), scale.data_ptr(),
+                                   shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), None, p2.data_ptr(), n, h, w, c, st))
+    if with_skip:
+        assert torch.equal(g2, da)     # the reduce-only pass wrote nothing
+    L.check(lib.oct_bn_bwd_apply_pool(eng.dt, L.ptr(g2 if with_skip else None), dpool.data_ptr(), y.data_ptr(), scale.data_ptr(),
+                                      shift.data_ptr(), coef.data_ptr(), g2.data_ptr(), n, h, w, c, st))
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2), "partial sums"
+    assert torch.equal(g1, g2), "dY"
