@@ -87,6 +87,17 @@ def prepack(dtype: str, module: torch.nn.Module) -> None:
             store[slot] = val
 
 
+NBT_PENDING = []   # BatchNorm step counters of the ops run since the last flush
+
+
+def flush_counters() -> None:
+    """num_batches_tracked += 1 for every train-mode BatchNorm op since the last call: ONE multi-tensor launch at the end of
+    a block's / network's forward (every public forward ends in to_nchw) instead of one 5-us launch per layer."""
+    if NBT_PENDING:
+        torch._foreach_add_(NBT_PENDING, 1)
+        NBT_PENDING.clear()
+
+
 def _need_cuda(t: torch.Tensor):
     if t.device.type != "cuda":
         raise L.OctError("the HIP path needs a device tensor (there is no CPU fallback)")
@@ -121,6 +132,7 @@ class ToNCHW(torch.autograd.Function):
         a = a.contiguous()
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=a.device)
         L.check(L.lib().oct_nhwc_to_nchw(e.dt, a.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "oct_nhwc_to_nchw")
+        flush_counters()
         ctx.dtype = dtype
         return out
 
@@ -215,7 +227,7 @@ class ConvAffineAct(torch.autograd.Function):
                                         beta.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(),
                                         bn.running_var.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                         scale.data_ptr(), shift.data_ptr(), L.ptr(cbias), _stream()), "oct_bn_finalize")
-            bn.num_batches_tracked.add_(1)
+            NBT_PENDING.append(bn.num_batches_tracked)   # bumped by one multi-tensor launch (flush_counters)
         else:
             conv()
             if bn is not None:
@@ -223,12 +235,9 @@ class ConvAffineAct(torch.autograd.Function):
                                                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_EPS,
                                                scale.data_ptr(), shift.data_ptr(), L.ptr(cbias), _stream()),
                         "oct_bn_eval_coeffs")
-            else:
-                scale.fill_(1.0)
-                if cbias is not None:
-                    shift.copy_(cbias.detach())
-                else:
-                    shift.zero_()
+            else:   # bare convolution (+ bias): constants instead of three tiny fill / copy launches per op
+                scale = e._const(1.0, cout, dev)
+                shift = cbias.detach() if cbias is not None else e._const(0.0, cout, dev)
         ctx.cfg = (dtype, bn, act, taps, train_bn, res is not None, cbias is not None, kk, lazy)
         ctx.xf = (xf0, xf1)
         ctx.rowdot = rowdot
