@@ -106,6 +106,7 @@ def parse_args(argv=None):
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive side measurement (N = 1)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 parity-mode side measurement (N = 1)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercise the multi-rank plumbing on CPU tensors")
     ap.add_argument("--bucket-mb", type=float, default=3.0, help="gradient bucket threshold (MB)")
@@ -209,6 +210,7 @@ def dry_run(args, rank, world):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tt.item() / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
             "dry_run": True, "backend": dist.get_backend() if world > 1 else None,
+            "world_size_seen": dist.get_world_size() if world > 1 else 1,
             "allreduce_ok": ok, "params_identical_after_broadcast": same,
             "buckets": [[lo, hi] for _, lo, hi in red.buckets],
             "bucket_launch_order": [k for k, _, _ in red.launch_log[:len(red.buckets)]],
@@ -448,6 +450,34 @@ def pcie_inclusive(args, trainer, x, t):
             "how": "pinned host batch -> device on a copy stream, double buffered, overlapped with the previous step"}
 
 
+def parity_mode_rate(args, dev, x, t):
+    """The same training step in compute_dtype="f32" (fp32 activations, v_mfma_f32_32x32x2_f32): the mode the parity
+    tests assert arg-max identity and Dice / IoU within 1e-5 in.  A few steps; never `value`."""
+    import torch
+    from retinal_oct_image_segmentation_via_deep_learning_amd import UNet, ddp
+    torch.manual_seed(0)
+    model = UNet(1, args.classes, init_features=args.features, compute_dtype="f32").to(dev).train()
+    trainer = ddp.DataParallelTrainer(model, lr=0.01, momentum=0.9)
+    b = min(args.batch, 8)          # fp32 activations of batch 32 would double the resident set for a side figure
+    xs, ts = x[:b].contiguous(), t[:b].contiguous()
+    for _ in range(2):
+        trainer.step(xs, ts)
+    torch.cuda.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(xs, ts)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"value": round(b * steps / el, 2), "unit": "B-scans/s", "ms_per_step": round(el / steps * 1e3, 3), "batch": b,
+           "steps": steps, "dtype": "f32",
+           "how": "compute_dtype='f32': the same kernels' generic path with fp32 storage and exact fp32 MFMA; the precision of "
+                  "the arg-max / Dice parity contract (tests/test_gpu_unet.py, test_gpu_fullsize.py)"}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def worker(args) -> int:
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
@@ -455,6 +485,9 @@ def worker(args) -> int:
               file=sys.stderr)
         return 2
 
+    if os.environ.get("OCT_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):   # test hook: a rank that dies before rendezvous
+        print("bench.py: OCT_BENCH_FAIL_RANK: this rank exits before the rendezvous", file=sys.stderr)
+        return 3
     import torch
     import torch.distributed as dist
     from retinal_oct_image_segmentation_via_deep_learning_amd import UNet, ddp
@@ -496,9 +529,13 @@ def worker(args) -> int:
         loss = trainer.step(x, t)
     sync()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3] * 2        # [min, max] over ranks of the per-rank mean step time
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        lo = tt.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        rank_ms = [lo.item() / args.steps * 1e3, tt.item() / args.steps * 1e3]
         elapsed = tt.item()
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
@@ -523,7 +560,8 @@ def worker(args) -> int:
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-        "kernel": "igemm_kernel + wgrad_kernel (conv stack, %d launches/step)" % len(prof),
+        "kernel": "igemm2_kernel + wgrad2_kernel + first_fprop_mfma_kernel + first_wgrad_mfma_kernel (conv stack: every "
+                  "convolution / transposed convolution launch of the step except the 1x1 head, %d launches/step)" % len(prof),
         "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
         "flop_per_launch": flops_bscan * args.batch / max(len(prof), 1),
         "conv_ms_per_step": round(conv_ms, 3),
@@ -535,6 +573,12 @@ def worker(args) -> int:
     if world == 1 and not args.no_h2d:
         pcie = pcie_inclusive(args, trainer, x, t)
 
+    # the precision the parity contract is stated in (arg-max identical / Dice within 1e-5: fp32 storage, exact fp32 MFMA):
+    # the same step, a few iterations, so that its cost is visible next to the bf16 headline
+    parity = None
+    if world == 1 and not args.no_parity_mode:
+        parity = parity_mode_rate(args, dev, x, t)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -545,6 +589,9 @@ def worker(args) -> int:
             "unit": "B-scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "backend": dist.get_backend() if (world > 1 and dist.is_initialized()) else None,
+            "world_size_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            "rank_ms_per_step": {"min": round(rank_ms[0], 3), "max": round(rank_ms[1], 3)},
             "config": {"workload": f"SOTAS/Layers_Segment UNet(1,{args.classes},init_features={args.features}) "
                                    f"train step, {args.height}x{args.width}, batch {args.batch}/GPU "
                                    f"(BASELINE configs[1]{'/[2] data-parallel' if world > 1 else ''})",
@@ -555,7 +602,7 @@ def worker(args) -> int:
                        "grad_buckets_bytes": [4 * (hi - lo) for _, lo, hi in trainer.reducer.buckets],
                        "hip_graph": graph_used, "hip_graph_error": trainer.graph_error},
             "loss": float(loss[0].item()),
-            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
+            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "parity_mode": parity,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

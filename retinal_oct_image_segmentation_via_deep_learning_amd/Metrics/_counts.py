@@ -59,6 +59,12 @@ def _prepare(y_true, y_pred, device=None):
     yp = yp.to(device=dev, dtype=tdt).contiguous()
     if yt.device.type != "cuda":
         raise L.OctError("Metrics need a GPU: there is no CPU fallback on the product path")
+    # the kernels read 16-B vectors: a contiguous VIEW at an odd storage offset (masks[i] of a uint8 batch of 101x101
+    # images, flat[1:]) passes .contiguous() unchanged -- the reference's numpy metric computes there, so copy
+    if yt.data_ptr() & 15:
+        yt = yt.clone()
+    if yp.data_ptr() & 15:
+        yp = yp.clone()
     return yt, yp, np.dtype(npdt), kdt
 
 
@@ -91,22 +97,31 @@ _last = {"key": None, "val": None}   # one entry: the eval loop pattern is "seve
 launch_count = [0]                     # confusion-kernel passes issued (tests assert the one-pass property)
 
 
-def _cache_key(y_true, y_pred):
+def _cache_key(y_true, y_pred, device=None):
+    """Identity + torch's version counters + data pointers + the requested device.  Writes that bypass the version counter
+    (a HIP-graph replay into a static buffer, a raw-pointer kernel of this library, `.data` / DLPack writes) are NOT seen:
+    call `invalidate()` after such a write."""
     if isinstance(y_true, torch.Tensor) and isinstance(y_pred, torch.Tensor) and y_true.is_cuda and y_pred.is_cuda:
-        return (weakref.ref(y_true), y_true._version, weakref.ref(y_pred), y_pred._version)
+        return (weakref.ref(y_true), y_true._version, weakref.ref(y_pred), y_pred._version, y_true.data_ptr(), y_pred.data_ptr(),
+                str(device) if device is not None else None, L.param_generation[0])
     return None
+
+
+def invalidate():
+    """Forget the cached counts (out-of-band writes into the cached tensors)."""
+    _last["key"], _last["val"] = None, None
 
 
 def _cache_hit(key):
     k = _last["key"]
     return (k is not None and key is not None and k[0]() is not None and k[0]() is key[0]() and k[2]() is key[2]()
-            and k[1] == key[1] and k[3] == key[3])
+            and k[1] == key[1] and k[3] == key[3] and k[4:] == key[4:])
 
 
 def confusion_sums(y_true, y_pred, device=None):
     """Returns (sums, n, float32_result): sums = [tp, t, p, tn, fp, fn] as python ints (integer
     masks, exact) or floats (float masks, fp64 accumulation)."""
-    key = _cache_key(y_true, y_pred)
+    key = _cache_key(y_true, y_pred, device)
     if _cache_hit(key):
         return _last["val"]
     yt, yp, npdt, kdt = _prepare(y_true, y_pred, device)

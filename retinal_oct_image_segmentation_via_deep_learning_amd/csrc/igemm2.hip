@@ -61,38 +61,64 @@ __device__ __forceinline__ float bf16hi(unsigned u) { return __uint_as_float(u &
 // D3: the depth taps / image maps of the volumetric network (OctConvDesc.depth, out_img_*).  A template switch, not a
 // runtime one: the same code guarded by `p.depth > 0` inside the producers' issue path cost the 2-D benchmark 12 % of
 // its igemm2 time (measured: 13.7 -> 15.4 ms per step), these kernels being bound by exactly that path.
-template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS, bool RAGGED = false, bool D3 = false>
+#ifndef IG2_M16
+#define IG2_M16 1
+#endif
+#ifndef IG2_M16_NF1
+#define IG2_M16_NF1 0
+#endif
+#ifndef IG2_PIXB16
+#define IG2_PIXB16 96
+#endif
+// which instantiations multiply with v_mfma_f32_16x16x32_bf16 (see M16 in the kernel)
+template <int TAPS, int NF, bool WRES> constexpr bool ig2_m16() { return IG2_M16 && TAPS == 9 && !WRES && (NF == 2 || IG2_M16_NF1); }
+// Pixel pitch of the LDS halo tile (bytes; 32 bf16 = 64 B of payload).  Register staging pads the pixel so that a wave's
+// ds_read_b128 of one fragment touches every bank once -- and which pad does that depends on the lane -> pixel map of the
+// MFMA shape (bank model of MI355X_MICROARCH.md, LDS: ds_read_b128 is serviced in four 16-lane groups):
+//   32x32x16 (lane = pixel l & 31, k half l >> 5):        80 B: 4 LDS cycles per read   (96 B: 8)
+//   16x16x32 (lane = pixel l & 15, k quarter l >> 4):     96 B: 4 LDS cycles per read   (80 B: 8 -- the pitch round 2 ran the
+//                                                          16x16x32 kernels on: every activation read paid a 2-way conflict)
+// DMA tiles are dense (64 B) with the swizzle on the source address.  tools/lds_swizzle_check.py enumerates all of these.
+template <int TAPS, int NF, bool WRES, bool DMA> constexpr int ig2_pixb() { return DMA ? 64 : (ig2_m16<TAPS, NF, WRES>() ? IG2_PIXB16 : 80); }
+
+// 16 zero bytes in device memory: the source of every LDS-DMA lane whose pixel is padding (a DMA cannot write a constant)
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
+
+// DMA (data gradients: the input dY needs no transform on load): the halo tile goes global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, 1 KB per wave instruction, no registers, no ds_write).  A DMA writes LDS linearly in lane
+// order, so the tile is dense ([pixel][64 B], no pad) and the bank-conflict swizzle moves to the SOURCE address: the 16-B
+// chunk stored at position c of pixel (row, col) is channel chunk c ^ key(col), key = (col >> KSH) & 3 with KSH = 2 for
+// the 32x32x16 read pattern and 1 for the 16x16x32 one (each conflict-free for all three tap columns; exhaustive check in
+// tools/lds_swizzle_check.py).  Three (3x3) or six (1x1) LDS buffers: the DMAs of stage s + NBUF - 1 are issued while stage s
+// multiplies, the producers wait with a COUNTED vmcnt for stage s + 1 and the stage barrier is a raw s_barrier.
+template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS, bool RAGGED = false, bool D3 = false, bool DMA = false>
 __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   static_assert(WM * WN == 4, "four MFMA waves");
+  static_assert(!DMA || (!WRES && !STATS && !RAGGED && !D3), "DMA staging: streamed weights, whole tiles, 2-D, no BatchNorm sums");
   constexpr int TH = WM * MF, TW = 32;
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr int NPIX = LH * LW;
-  constexpr int PIXB = 80;                      // 32 bf16 + 16 B pad: conflict-free ds_read_b128
-  constexpr int BUFB = NPIX * PIXB;
   constexpr int NSLOT = (NPIX + 63) / 64;       // producers (4 waves): 64 pixels x 4 channel groups per pass
+  constexpr int PIXB = ig2_pixb<TAPS, NF, WRES, DMA>();
+  constexpr int BUFB = DMA ? NSLOT * 4096 : NPIX * PIXB;
+  constexpr int NBUF = DMA ? (TAPS == 9 ? 3 : 6) : 2;
   constexpr int NT = WN * NF * 32;
   constexpr int KSTEPS = TAPS * 2;              // k16 steps per 32-channel chunk
-#ifndef IG2_M16
-#define IG2_M16 1
-#endif
   // M16: the streamed-weight 3x3 kernels multiply with v_mfma_f32_16x16x32_bf16 -- 18 half-steps (tap, 16-pixel half) of
   // MF * 2NF MFMAs per stage instead of 18 k16 steps of MF * NF.  Same FLOPs per cycle, same LDS and weight bytes, same
   // packed-weight layout (a lane gathers its 16 B from the 32x32x16 fragment order); an accumulator acc[m][q] holds four
   // 16x16 blocks, register 4*S + e of quarter S = 2*half + cc = channel 16*cc + 4*(lane>>4) + e at pixel 16*half + (lane&15).
   // Why: these kernels are power-bound and the chip holds a higher clock on this shape -- a timing-only
   // build that issued the same FLOPs as 16x16x32 measured -9 % on fprop / dgrad of the Cout >= 128 layers.
-#ifndef IG2_M16_NF1
-#define IG2_M16_NF1 0
-#endif
-  constexpr bool M16 = IG2_M16 && TAPS == 9 && !WRES && (NF == 2 || IG2_M16_NF1);   // NF == 1: 5-12 % slower with the deferred epilogue riding on the half-steps,
+  constexpr bool M16 = ig2_m16<TAPS, NF, WRES>();   // NF == 1: 5-12 % slower with the deferred epilogue riding on the half-steps,
                                                                                     // +0.06 ms per step with the un-deferred one (-DIG2_M16_NF1=1): stays on 32x32x16
   typedef Mma<bf16_t> M;
   typedef M::Frag Frag;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const buf0 = smem;
-  float* const wg_stats = reinterpret_cast<float*>(smem + 2 * BUFB);  // [2 parity][WM][2][NT]
+  float* const wg_stats = reinterpret_cast<float*>(smem + NBUF * BUFB);  // [2 parity][WM][2][NT]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: everything derived from it stays scalar
@@ -122,9 +148,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // BN scale/shift of every input channel live in LDS: reading them with ds_read keeps them off the
   // vmcnt queue (a global load issued at commit time would be YOUNGER than the prefetched stages and
   // waiting for it would drain the whole ring -- vmcnt retires in order)
-  float* const sxf = reinterpret_cast<float*>(smem + 2 * BUFB) + (2 * WM * 2 * NT + 4);
-  unsigned char* const oscr = smem + 2 * BUFB + (2 * WM * 2 * NT + 4) * 4 + 2 * 1024 * 4;  // 2 slots x 4 waves x 32 px x 80 B
-  static_assert((2 * BUFB + (2 * WM * 2 * NT + 4) * 4) % 16 == 0, "scratch must stay 16-B aligned");
+  float* const sxf = reinterpret_cast<float*>(smem + NBUF * BUFB) + (2 * WM * 2 * NT + 4);
+  unsigned char* const oscr = smem + NBUF * BUFB + (2 * WM * 2 * NT + 4) * 4 + 2 * 1024 * 4;  // 2 slots x 4 waves x 32 px x 80 B
+  static_assert((NBUF * BUFB + (2 * WM * 2 * NT + 4) * 4) % 16 == 0, "scratch must stay 16-B aligned");
   float* const sbias = reinterpret_cast<float*>(oscr + 2 * 4 * 32 * 80);   // [cout/4] deconv bias (D2S only)
   // streamed-weight kernels: BatchNorm partial sums of ALL items of this workgroup, [2][cout]; one row
   // per workgroup reaches memory instead of one per tile (bn_finalize then reads <= 512 rows, not 16 k)
@@ -145,6 +171,88 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   }
   __syncthreads();
 
+  if constexpr (DMA) {
+   if (wave >= 4) {
+    // ====================== producer waves (4), LDS-DMA staging: no registers, no commit ======================
+    const int ptid = tid - 256, grp = ptid & 3, pbase = ptid >> 2;
+    constexpr int KSH = M16 ? 1 : 2;
+    const unsigned cs2 = 2u * (unsigned)p.c0;           // one source, no transform (checked by the host)
+    unsigned goff[NSLOT], code[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int pix = pbase + 64 * i;
+      const int ly = pix / LW, lx = pix - ly * LW;
+      const int relp = s2d ? (2 * ly) * (2 * p.w) + 2 * lx : ly * p.w + lx;   // relative to the halo corner
+      goff[i] = (unsigned)relp * cs2 + (unsigned)((grp ^ ((lx >> KSH) & 3)) * 16);
+      unsigned c = pix >= NPIX ? 16u : 0u;
+      if (HALO) c |= (ly == 0 ? 1u : 0u) | (lx == 0 ? 4u : 0u) | (ly == LH - 1 ? 2u : 0u) | (lx == LW - 1 ? 8u : 0u);
+      code[i] = c;
+    }
+    const int last = nstage - 1;
+    int i_sidx = 0, i_ch = 0, i_nbi, i_txi, i_tyi, i_img;
+    {
+      int t = t_first;
+      i_nbi = nbi_first;
+      i_txi = t % p.tiles_x; t /= p.tiles_x;
+      i_tyi = t % p.tiles_y; i_img = t / p.tiles_y;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gl_void;
+    const unsigned char* const zsrc = reinterpret_cast<const unsigned char*>(g_zero16);
+    const int pw = wave - 4;
+    auto dma = [&](unsigned char* buf) {   // the next stage (counters as in the register path below) -> buf
+      const int ch = i_ch, txi = i_txi, tyi = i_tyi, img = i_img;
+      if (i_sidx < last) {
+        ++i_sidx;
+        if (++i_ch == p.nch) {
+          i_ch = 0;
+          if (++i_nbi == p.nblk) {
+            i_nbi = 0;
+            i_txi += sx; if (i_txi >= p.tiles_x) { i_txi -= p.tiles_x; ++i_tyi; }
+            i_tyi += sy; if (i_tyi >= p.tiles_y) { i_tyi -= p.tiles_y; ++i_img; }
+            i_img += simg;
+          }
+        }
+      }
+      const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
+                            (txi == p.tiles_x - 1 ? 8u : 0u);
+      const bf16_t* base;
+      if (s2d) {  // k = (dy*2+dx)*C + c of the 2H x 2W tensor
+        const int dydx = (ch * 32) / p.c0;
+        const int cc = ch * 32 - dydx * p.c0;
+        const size_t o2 = ((size_t)img * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
+        base = p.x0 + o2 * p.c0 + cc;
+      } else {
+        base = p.x0 + (((size_t)img * p.h + tyi * TH) * p.w + txi * TW) * p.c0 + ch * 32;
+      }
+      // the tile's halo corner (it may lie outside the tensor: such lanes read the zero block instead)
+      const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - (size_t)(HALO * (p.w + 1)) * cs2;
+      unsigned char* const dst = buf + pw * 1024;
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        const bool ok = (code[i] & edge) == 0;
+        const unsigned char* src = ok ? hb + goff[i] : zsrc;
+        __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)(dst + i * 4096), 16, 0, 0);
+      }
+    };
+    // all but the youngest NBUF - 2 stages have landed (vmcnt = simm16[15:14 | 3:0]); then the raw barrier
+    constexpr int NW = NSLOT * (NBUF - 2);
+    static_assert(NW < 64, "vmcnt is a 6-bit counter");
+    auto stage_barrier = [&]() {
+      __builtin_amdgcn_s_waitcnt((NW & 15) | ((NW >> 4) << 14) | (7 << 4) | (15 << 8));
+      asm volatile("s_barrier" ::: "memory");
+    };
+    int wb = 0;   // buffer of the next stage to fetch
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) { dma(buf0 + wb * BUFB); wb = wb + 1 == NBUF ? 0 : wb + 1; }
+    stage_barrier();   // stage 0 is in LDS
+    for (int s0 = 0; s0 < nstage_pad; ++s0) {   // while stage s0 multiplies: fetch stage s0 + NBUF - 1 into the buffer stage s0 - 1 left
+      dma(buf0 + wb * BUFB); wb = wb + 1 == NBUF ? 0 : wb + 1;
+      stage_barrier();
+    }
+    return;
+   }
+  } else
   if (wave >= 4) {
     // =============================== producer waves (4) ===============================
     // global -> registers (issued two stages ahead) -> BN+ReLU -> LDS halo tile of the next stage
@@ -446,6 +554,34 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #endif
     }
   };
+#ifndef IG2_PERM_EPI
+#define IG2_PERM_EPI 1
+#endif
+  // 16x16x32 accumulators leave WITHOUT the LDS transpose: lane (r16, kg) holds, per channel half cc, channels 16cc + 4kg ..+3
+  // of pixel r16 (quarter half 0) and of pixel 16 + r16 (half 1) -- v_permlane16_swap trades the half-1 piece of the even kg
+  // rows for the half-0 piece of the odd ones, after which a lane owns 8 consecutive channels (16 B) of ONE pixel:
+  // pixel 16*(kg&1) + r16, channels 16cc + 8*(kg>>1).  Two 16-B stores per fragment, every pixel's 32 B written by two
+  // neighbouring lanes; no ds_write / ds_read / lgkmcnt round trips (the un-deferred eight-fragment epilogue through LDS was
+  // 4.7-5.0 k cycles per item with the matrix pipe idle: profiles/r03_ig2_traces.txt).
+  constexpr bool PERM_EPI = IG2_PERM_EPI && M16 && !DEFER;
+  auto frag_store_perm = [&](int m, int q, const unsigned (&pk)[8]) {
+    if (RAGGED && e_tyi * TH + wm * MF + m >= p.h) return;   // ragged last tile row (wave-uniform)
+    const int wlim = (RAGGED && (e_txi + 1) * TW > p.w) ? p.w - e_txi * TW : TW;
+    const int kg = lane >> 4, r16 = lane & 15;
+    const int px = 16 * (kg & 1) + r16;
+    unsigned char* const fb = e_fb[q] + (size_t)m * e_rowb[q];
+    const unsigned loff = __umul24((unsigned)px, e_pstep[q]) + (unsigned)(kg >> 1) * 16u;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      // quarters S = cc (pixel half 0) and 2 + cc (pixel half 1): two dwords each
+      unsigned a0 = pk[2 * cc], a1 = pk[2 * cc + 1], b0 = pk[2 * (2 + cc)], b1 = pk[2 * (2 + cc) + 1];
+      auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+      auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+      const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+      if (RAGGED && px >= wlim) continue;   // ragged last tile column
+      *reinterpret_cast<u32x4*>(fb + (loff + (unsigned)cc * 32u)) = v;
+    }
+  };
   auto store_frag = [&](int m, int q) {   // fragment (m, q) of the item recorded by set_item, back to back
     u32x4 tv[2];
     frag_to_lds(packed[DEFER ? m : 0][DEFER ? q : 0]);
@@ -579,10 +715,44 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
         return ((m + ty) * LW + tx) * PIXB + k16 * 32;
       };
+      // DMA tiles (dense, swizzled): the chunk position depends on the tile column r + tx, so each (tx, k16) has its own
+      // lane base; the row (m + ty) stays a compile-time offset
+      constexpr int NTX = (TAPS == 9) ? 3 : 1;
+      const unsigned char* lbs[DMA ? NTX : 1][2];
+      if constexpr (DMA && !M16) {
+#pragma unroll
+        for (int tx = 0; tx < NTX; ++tx)
+#pragma unroll
+          for (int k16 = 0; k16 < 2; ++k16) {
+            const int col = r + tx;
+            lbs[tx][k16] = tb + ((wm * MF) * LW + col) * 64 + (((2 * k16 + hh) ^ ((col >> 2) & 3)) * 16);
+          }
+      }
+      auto xptr = [&](int s, int m) -> const unsigned char* {
+        if constexpr (DMA) {
+          const int tap = s >> 1, k16 = s & 1;
+          const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
+          return lbs[tx][k16] + (m + ty) * LW * 64;
+        } else return lb + xoff(s, m);
+      };
       if constexpr (M16) {
         const int r16 = lane & 15, kg = lane >> 4;
         const unsigned char* lb16 = tb + ((wm * MF) * LW + r16) * PIXB + kg * 16;
         auto boff = [](int u, int m) constexpr { const int t = u >> 1; return ((m + t / 3) * LW + t % 3 + 16 * (u & 1)) * PIXB; };
+        const unsigned char* lbs16[DMA ? 3 : 1][2];   // DMA tiles: lane base per (tap column, pixel half), key = (col >> 1) & 3
+        if constexpr (DMA) {
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const int col = r16 + 16 * hf + tx;
+              lbs16[tx][hf] = tb + ((wm * MF) * LW + col) * 64 + ((kg ^ ((col >> 1) & 3)) * 16);
+            }
+        }
+        auto bptr = [&](int u, int m) -> const unsigned char* {
+          if constexpr (DMA) { const int t = u >> 1; return lbs16[t % 3][u & 1] + (m + t / 3) * LW * 64; }
+          else return lb16 + boff(u, m);
+        };
         // this lane's 16 B of a weight fragment pair: rows 16*cc + r16 of k16 fragment kg>>1, k half kg&1 (32x32x16 order)
         const int lpart = (kg >> 1) * 512 + ((kg & 1) * 32 + r16) * 8 - lane * 8;   // wbase / wbase_n carry lane*8
         auto aoff = [&](int c) { return (size_t)(c >> 1) * qstride + (c & 1) * 128 + lpart; };
@@ -595,13 +765,13 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         }
         Frag b16[2][MF];
 #pragma unroll
-        for (int m = 0; m < MF; ++m) b16[0][m] = M::load(lb16 + boff(0, m));
+        for (int m = 0; m < MF; ++m) b16[0][m] = M::load(bptr(0, m));
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {   // half-step s = 2*tap + pixel half
           const int t = s >> 1;
           if (s + 1 < KSTEPS) {
 #pragma unroll
-            for (int m = 0; m < MF; ++m) b16[(s + 1) & 1][m] = M::load(lb16 + boff(s + 1, m));
+            for (int m = 0; m < MF; ++m) b16[(s + 1) & 1][m] = M::load(bptr(s + 1, m));
           }
 #ifndef ABL_NO_WLOAD
           if ((s & 1) == 0) {   // weights of tap t + 1 (the next stage's tap 0 under this one's last)
@@ -639,12 +809,12 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #pragma unroll
       for (int j = 0; j < LD; ++j)
 #pragma unroll
-        for (int m = 0; m < MF; ++m) xr[j][m] = M::load(lb + xoff(j, m));
+        for (int m = 0; m < MF; ++m) xr[j][m] = M::load(xptr(j, m));
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
         if (s + LD < KSTEPS) {
 #pragma unroll
-          for (int m = 0; m < MF; ++m) xr[(s + LD) % (LD + 1)][m] = M::load(lb + xoff(s + LD, m));
+          for (int m = 0; m < MF; ++m) xr[(s + LD) % (LD + 1)][m] = M::load(xptr(s + LD, m));
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the reads of step s+LD ahead of the MFMAs of step s
 #pragma unroll
@@ -732,7 +902,8 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
               packed[DEFER ? m : 0][DEFER ? q : 0][2 * g + 1] = pack_bf16x2(acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]);
             }
           }
-          if (!DEFER) {
+          if (PERM_EPI) frag_store_perm(m, q, packed[0][0]);
+          else if (!DEFER) {
             frag_to_lds(packed[0][0], fidx & 1);
             if (pm_ >= 0) { frag_from_lds(tvp, (fidx - 1) & 1); frag_store(pm_, pq_, tvp); }
             pm_ = m; pq_ = q; ++fidx;
@@ -746,7 +917,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           }
         }
       }
-      if (!DEFER) { frag_from_lds(tvp, (fidx - 1) & 1); frag_store(pm_, pq_, tvp); }
+      if (!DEFER && !PERM_EPI) { frag_from_lds(tvp, (fidx - 1) & 1); frag_store(pm_, pq_, tvp); }
       if (DEFER) { set_item(img, tyi, txi, nbi); pend = true; }
       if (STATS && !WRES) {
         float* ws = wg_stats + parity * (WM * 2 * NT);
@@ -789,7 +960,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #ifdef OCT_TRACE
     if (p.trace && blockIdx.x == 0 && wave == 0 && lane == 0 && sidx == nstage - 1) p.trace[2044] = __builtin_amdgcn_s_memrealtime();
 #endif
-    cur ^= 1;
+    cur = DMA ? (cur + 1 == NBUF ? 0 : cur + 1) : (cur ^ 1);
     if (++ch == p.nch) {
       ch = 0; ++item;
       if (++nbi_c == p.nblk) {
@@ -908,8 +1079,24 @@ int oct_conv_v2_stat_rows(const OctConvDesc* d) {
 template <int WM, int WN, int MF, int NF, bool WRES>
 static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 2 * 4 * 32 * 80 + 1024 * (int)sizeof(float) +
+  const int lds = 2 * (TH + 2) * 34 * ig2_pixb<9, NF, WRES, false>() + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 2 * 4 * 32 * 80 + 1024 * (int)sizeof(float) +
                   (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
+  {
+    // > 64 KB of dynamic LDS: opt in once per instantiation (all eight variants of this shape share the size class)
+    static bool attr = false;
+    if (!attr) {
+      const int cap = 160 * 1024;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, WRES, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, WRES, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      if constexpr (!WRES) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      }
+      attr = true;
+    }
+  }
   const bool ragged = (p.w % 32) != 0 || (p.h % TH) != 0;
   if (p.depth > 0) {   // volumetric: whole tiles only (plan_v2), streamed weights
     if constexpr (!WRES) {
@@ -939,6 +1126,27 @@ static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
     hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(512), lds, s, p);
 }
 
+// LDS-DMA staging (see the kernel): data gradients -- one source, no transform on load, whole 8-row tiles, streamed weights
+static bool dma_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("OCT_IG2_DMA"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+template <int TAPS, int WM, int WN, int MF, int NF>
+static void launch_v2_dma(const Igemm2Params& p, int grid, hipStream_t s) {
+  constexpr int TH = WM * MF, HALO = TAPS == 9 ? 1 : 0;
+  constexpr int NSLOT = ((TH + 2 * HALO) * (32 + 2 * HALO) + 63) / 64, NBUF = TAPS == 9 ? 3 : 6;
+  constexpr int lds = NBUF * NSLOT * 4096 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 2 * 4 * 32 * 80 + 1024 * (int)sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<TAPS, WM, WN, MF, NF, false, false, false, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((igemm2_kernel<TAPS, WM, WN, MF, NF, false, false, false, false, true>), dim3(grid), dim3(512), lds, s, p);
+}
+
 // returns 1 when the launch was taken by this path, 0 when the shape is not eligible, <0 on error
 int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
   const V2Plan pl = plan_v2(d);
@@ -963,7 +1171,13 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
   p.depth = d->depth; p.nchc = (d->c0 + d->c1) / 32; p.oimg_mul = d->out_img_mul; p.oimg_add = d->out_img_add;
   if (p.depth > 0 && p.oimg_mul == 0) p.oimg_mul = 1;   // the D3 instantiation always applies the image map
   hipStream_t s = as_stream(stream);
-  if (d->taps == 1) {
+  const bool dma = dma_enabled() && !d->xform0 && !d->xform1 && d->c1 == 0 && !d->want_stats && !pl.wres && pl.th == 8 &&
+                   d->depth == 0 && d->out_img_mul == 0 && (d->w % 32) == 0 && (d->h % 8) == 0 && pl.nt >= 64 &&
+                   ((d->taps == 9) || (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN));
+  if (dma) {
+    if (d->taps == 9) { if (pl.nt == 64) launch_v2_dma<9, 2, 2, 4, 1>(p, pl.grid, s); else launch_v2_dma<9, 2, 2, 4, 2>(p, pl.grid, s); }
+    else { if (pl.nt == 64) launch_v2_dma<1, 2, 2, 4, 1>(p, pl.grid, s); else launch_v2_dma<1, 2, 2, 4, 2>(p, pl.grid, s); }
+  } else if (d->taps == 1) {
     if (pl.nt == 32) launch_v2_1x1<4, 1, 2, 1>(p, pl.grid, s);
     else if (pl.nt == 64) launch_v2_1x1<2, 2, 4, 1>(p, pl.grid, s);
     else launch_v2_1x1<2, 2, 4, 2>(p, pl.grid, s);

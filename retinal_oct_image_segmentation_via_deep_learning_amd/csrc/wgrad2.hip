@@ -65,6 +65,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// the same with the two reads addressed separately (swizzled tiles: the second read's half can differ per lane)
+__device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* first, const unsigned char* second) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(first));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(second));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // D3: depth shift of the input tile / image map of an S2D dY (volumetric network) -- compile-time, see igemm2.hip
 template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false>
 __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
@@ -74,6 +84,31 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   constexpr int NPI = LH * LW, NPD = TH * TW;          // pixels of the input / dY tile
   constexpr int INB = NPI * 64, DYB = NPD * 64;        // bytes per 32-channel block
   constexpr int STAGEB = IB * INB + CB * DYB;
+#ifndef W2_DYDMA
+#define W2_DYDMA 0   /* measured (r3, same box): +3.5 % on the weight-gradient launches, see DESIGN.md */
+#endif
+  // DMA: dY needs no transform on the way in and its LDS image ([pixel][64 B], dense) is exactly the order in which the
+  // producer lanes fetch it, so it goes global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave instruction): no
+  // registers, no ds_write, no commit work -- the producers' commit + issue (5.76 k cycles per stage against 5.35 k of MFMA
+  // phase, profiles/r02_wgrad2_timeline.txt) was what the stage waited for.  Ragged tiles (dY rows beyond the image must
+  // read as zero) keep the register path.
+  constexpr bool DMA = W2_DYDMA && !RAGGED;
+#ifndef W2_M16
+#define W2_M16 1
+#endif
+#ifndef W2_SWZ
+#define W2_SWZ 1
+#endif
+  // W16 (3x3 kernels): v_mfma_f32_16x16x32_bf16 -- a fragment is 32 pixels (a whole tile row) x 16 channels, D = 16 co x 16 ci
+  // in quarter S = 2*(co half) + (ci half) of the tap's accumulator: register 4S + e = (co 16a + 4*(lane>>4) + e, ci 16b + (lane&15)).
+  // Same FLOPs, LDS reads and loop as the 32x32x16 form (pixel halves become channel halves); the chip holds a higher clock
+  // on this shape (igemm2.hip, M16).
+  constexpr bool W16 = W2_M16 && TAPS == 9;
+  // SWZ: in the W16 form the two 16-lane groups that a ds_read_b64_tr_b16 services together read pixels p and p + 8 of the SAME
+  // 32-byte channel half -- 512 B apart, i.e. the same banks: a 2-way conflict on every transposed read (4 LDS cycles instead
+  // of 2; tools/lds_swizzle_check.py).  Pixels whose tile column has bit 3 set therefore store their two 32-B halves swapped
+  // (chunk g at g ^ 2), and a reader lane takes half h ^ bit3(column).
+  constexpr bool SWZ = W2_SWZ && W16;
   // MULTI (1 x 1 kernels only: one accumulator per pair, 16 registers): 8 or 16 pairs per workgroup, the four waves as a
   // 2 x 2 grid over (co, ci), each owning WCB x WIB pairs of the same staged tile.  A 1 x 1 weight gradient is a plain GEMM
   // over the pixels with nothing but staging between memory and the matrix pipe: with 64 x 64 blocks the deep transposed
@@ -120,8 +155,9 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     constexpr int SIB = (NPI * 4 + 255) / 256;   // input slots per 32-channel block (256 producer threads)
     constexpr int SDB = (NPD * 4 + 255) / 256;   // dY slots per 32-row block
     constexpr int D = DRING;
-    struct Stage { u32x4 ri[IB][SIB]; u32x4 rd[CB][SDB]; unsigned vm[IB]; unsigned vd; };
+    struct Stage { u32x4 ri[IB][SIB]; u32x4 rd[DMA ? 1 : CB][DMA ? 1 : SDB]; unsigned vm[IB]; unsigned vd; int img, tyi, txi; };
     Stage R[D];
+    const int pw = __builtin_amdgcn_readfirstlane(wave) - 4;   // producer wave 0..3, scalar: the LDS-DMA destination is wave-uniform
     // per-slot constants (shared by all blocks): pixel offset from the tile origin + border code
     int reli[SIB], reld[SDB];
     unsigned code[SIB], dcode[SDB];   // bits 8-15 / 16-23: local row / column (ragged last tiles), low bits: halo flags
@@ -136,12 +172,14 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       unsigned c = pix >= NPI ? 16u : 0u;
       if (HALO) c |= (ly == 0 ? 1u : 0u) | (lx == 0 ? 4u : 0u);
       c |= (ly >= ylast ? 2u : 0u) | (lx >= xlast ? 8u : 0u);
-      code[j] = c;
+      code[j] = c | (SWZ ? (unsigned)(((lx >> 3) & 1) << 1) << 8 : 0u);   // bits 8-9: chunk swizzle of this pixel
     }
+    unsigned dswz[SDB];
 #pragma unroll
     for (int j = 0; j < SDB; ++j) {
       const int pix = pb + 64 * j;  // NPD is a multiple of 64: every dY slot is live
       const int ly = pix / TW, lx = pix - ly * TW;
+      dswz[j] = SWZ ? (unsigned)(((lx >> 3) & 1) << 1) : 0u;
       reld[j] = (p.dy_mode == OCT_IN_S2D) ? (2 * ly) * (2 * p.w) + 2 * lx : ly * p.w + lx;
       dcode[j] = RAGGED ? ((ly >= p.h - (p.tiles_y - 1) * TH ? 2u : 0u) | (lx >= p.w - (p.tiles_x - 1) * TW ? 8u : 0u)) : 0u;
     }
@@ -152,6 +190,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       const unsigned edge = 16u | (tyi == 0 ? 1u : 0u) | (tyi == p.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) |
                             (txi == p.tiles_x - 1 ? 8u : 0u);
       const size_t origin = ((size_t)img * p.h + tyi * TH) * p.w + txi * TW;
+      S.img = img; S.tyi = tyi; S.txi = txi;
       // 3-D: the input tile of this depth tap lies one slice up / down; outside the volume it is padding (the loads
       // then re-read the tile's own slice and every slot is marked dead)
       bool zok = true;
@@ -177,6 +216,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         }
         S.vm[blk] = vm;
       }
+      if constexpr (!DMA) {
 #pragma unroll
       for (int blk = 0; blk < CB; ++blk) {
         const int row = co_sb + blk * 32;  // GEMM row = output channel (or (dydx, co) for the deconv)
@@ -201,6 +241,43 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         }
         if (RAGGED) S.vd = vd;
       }
+      }
+    };
+    // dY tile of the stage whose coordinates `S` holds -> LDS, no registers in between.  Lane i of producer wave pw fetches
+    // the 16 B that belong at byte (256 j + 64 pw + i) * 16 of the block: one contiguous KB per instruction.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gl_void;
+    auto dma_dy = [&](unsigned char* buf, const Stage& S) {
+      const int img = S.img, tyi = S.tyi, txi = S.txi;
+#pragma unroll
+      for (int blk = 0; blk < CB; ++blk) {
+        const int row = co_sb + blk * 32;
+        const bf16_t* base;
+        int cs;
+        if (p.dy_mode == OCT_IN_S2D) {
+          cs = p.cout >> 2;
+          const int dydx = row / cs, co = row - dydx * cs;
+          const int img2 = (D3 && p.dy_mul) ? img * p.dy_mul + p.dy_add : img;
+          const size_t o2 = ((size_t)img2 * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
+          base = p.dy + o2 * cs + co;
+        } else {
+          cs = p.cout;
+          base = p.dy + (((size_t)img * p.h + tyi * TH) * p.w + txi * TW) * cs + row;
+        }
+        unsigned char* const dst = buf + IB * INB + blk * DYB + pw * 1024;
+#pragma unroll
+        for (int j = 0; j < SDB; ++j)   // a DMA writes LDS in lane order: the swizzle goes on the source chunk
+          __builtin_amdgcn_global_load_lds((gl_void*)(base + __mul24(reld[j], cs) + (int)(((unsigned)g ^ dswz[j]) * 8u)), (lds_void*)(dst + j * 4096), 16, 0, 0);
+      }
+    };
+    // s_waitcnt vmcnt(N), everything else at its maximum (gfx9 encoding: vmcnt = simm16[15:14 | 3:0])
+    constexpr int NXL = IB * SIB;   // input loads of one stage: issued AFTER the stage's DMA, they stay in flight across the wait
+    constexpr int WAIT_DMA = (NXL & 15) | ((NXL >> 4) << 14) | (7 << 4) | (0 << 8);   // ... and lgkmcnt(0): the commit's ds_writes
+    // Stage barrier of the producers.  With a DMA in the stage it is the counted wait + a raw s_barrier: __syncthreads()
+    // would add vmcnt(0) (the pending LDS write of a DMA sits on the VM counter) and drain the prefetched stages too.
+    auto stage_barrier = [&]() {
+      if constexpr (DMA) { __builtin_amdgcn_s_waitcnt(WAIT_DMA); asm volatile("s_barrier" ::: "memory"); }
+      else __syncthreads();
     };
     auto commit = [&](unsigned char* buf, const Stage& S) {
 #pragma unroll
@@ -233,10 +310,11 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
             const bool live = ((S.vm[blk] >> j) & 1u) != 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = live ? v[e] : 0u;
-            *reinterpret_cast<u32x4*>(buf + blk * INB + (pb + 64 * j) * 64 + g * 16) = v;
+            *reinterpret_cast<u32x4*>(buf + blk * INB + (pb + 64 * j) * 64 + ((unsigned)g ^ ((code[j] >> 8) & 3u)) * 16) = v;
           }
         }
       }
+      if constexpr (!DMA)
 #pragma unroll
       for (int blk = 0; blk < CB; ++blk)
 #pragma unroll
@@ -247,15 +325,19 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = live ? v[e] : 0u;
           }
-          *reinterpret_cast<u32x4*>(buf + IB * INB + blk * DYB + (pb + 64 * j) * 64 + g * 16) = v;
+          *reinterpret_cast<u32x4*>(buf + IB * INB + blk * DYB + (pb + 64 * j) * 64 + ((unsigned)g ^ dswz[j]) * 16) = v;
         }
     };
     const int last = nstage - 1;
 #pragma unroll
     for (int j = 0; j < D; ++j) issue(min(j, last), R[j]);
     commit(smem, R[0]);
+    if constexpr (DMA) dma_dy(smem, R[0]);
     issue(min(D, last), R[0]);
-    __syncthreads();
+    // The DMA sits between this stage's commit (whose registers were waited for with a COUNTED vmcnt: no DMA was pending
+    // then) and the next loads; the explicit wait retires it and leaves those loads in flight.  It must be the builtin:
+    // hipcc has to see the DMA retired, or every later wait of the ring becomes vmcnt(0).
+    stage_barrier();
     // branch-free steady state over the padded stage count (see igemm2.hip)
     for (int s0 = 0; s0 < nstage_pad; s0 += D) {
 #pragma unroll
@@ -263,10 +345,11 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         const int nx = s0 + j + 1;
         if (wave == 4) W2TRACE(4, nx - 1);
         commit(smem + (nx & 1) * STAGEB, R[(j + 1) % D]);
+        if constexpr (DMA) dma_dy(smem + (nx & 1) * STAGEB, R[(j + 1) % D]);   // stage nx's tile: buffer nx & 1 was last read in stage nx - 2
         if (wave == 4) W2TRACE(5, nx - 1);
         issue(min(nx + D, last), R[(j + 1) % D]);
         if (wave == 4) W2TRACE(6, nx - 1);
-        __syncthreads();
+        stage_barrier();
         if (wave == 4) W2TRACE(7, nx - 1);
       }
     }
@@ -278,18 +361,23 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   const int pair = MULTI ? 0 : wave % PAIRS, psx = MULTI ? 0 : wave / PAIRS;
   const int cb = MULTI ? (wave >> 1) * WCB : pair / IB, ib = MULTI ? (wave & 1) * WIB : pair % IB;   // MULTI: first pair of the wave's sub-block
   const int g4 = lane >> 4, li = lane & 15;
-#ifndef W2_M16
-#define W2_M16 1
-#endif
-  // W16 (3x3 kernels): v_mfma_f32_16x16x32_bf16 -- a fragment is 32 pixels (a whole tile row) x 16 channels, D = 16 co x 16 ci
-  // in quarter S = 2*(co half) + (ci half) of the tap's accumulator: register 4S + e = (co 16a + 4*(lane>>4) + e, ci 16b + (lane&15)).
-  // Same FLOPs, LDS reads and loop as the 32x32x16 form (pixel halves become channel halves); the chip holds a higher clock
-  // on this shape (igemm2.hip, M16).
-  constexpr bool W16 = W2_M16 && TAPS == 9;
   // transposed-read lane address inside a [pixel][64 B] block: pixel 8*(g4>>1) + (li>>2), channel 16*(g4&1) + 4*(li&3)
   // (W16: pixel 8*g4 + (li>>2), channel 4*(li&3) of the 16-channel half)
   const int lane_off = W16 ? (8 * g4 + (li >> 2)) * 64 + (4 * (li & 3)) * 2
                            : (8 * (g4 >> 1) + (li >> 2)) * 64 + (16 * (g4 & 1) + 4 * (li & 3)) * 2;
+  // SWZ: lane offsets with the channel half folded in.  lo1[h]: pixel 8*g4 + (li>>2) (tile column bit 3 = g4 & 1: the
+  // tap column tx <= 2 and li>>2 <= 3 cannot carry into it), half h ^ (g4 & 1).  lo2[tx-1][h]: the SECOND read of an input
+  // fragment (pixel + 4) at tap column tx = 1, 2, where tx + (li>>2) + 4 can reach 8 and flip the bit for some lanes.
+  int lo1[2], lo2[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    lo1[h] = lane_off + ((h ^ (g4 & 1)) * 32);
+#pragma unroll
+    for (int tx = 1; tx <= 2; ++tx) {
+      const int carry = ((tx + (li >> 2) + 4) >> 3) & 1;
+      lo2[tx - 1][h] = lane_off + 4 * 64 + ((h ^ (g4 & 1) ^ carry) * 32);
+    }
+  }
 
   constexpr int NACC = MULTI ? WCB * WIB : TAPS;
   f32x16 acc[NACC];
@@ -336,6 +424,22 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
                    : ((psx * ROWS + j / 6) * LW + ((j / 3) & 1) * 16 + j % 3) * 64;
       };
       auto ao = [&](int k) { return W16 ? ((psx * ROWS + (k >> 1)) * TW) * 64 + (k & 1) * 32 : a_off(k); };
+      // swizzled tiles: per-stage lane bases (the row / tap column of a fragment stays a compile-time DS offset)
+      const unsigned char* const in_b = smem + cur * STAGEB + ib * INB + (psx * ROWS) * LW * 64;
+      const unsigned char* const dy_b = smem + cur * STAGEB + IB * INB + cb * DYB + (psx * ROWS) * TW * 64;
+      const unsigned char* in1[2] = {in_b + lo1[0], in_b + lo1[1]};
+      const unsigned char* in2[2][2] = {{in_b + lo2[0][0], in_b + lo2[0][1]}, {in_b + lo2[1][0], in_b + lo2[1][1]}};
+      const unsigned char* dy1[2] = {dy_b + lo1[0], dy_b + lo1[1]};
+      auto in_frag = [&](int j) -> bf16x8 {
+        if constexpr (SWZ) {
+          const int h = (j / 3) & 1, tx = j % 3, rc = ((j / 6) * LW + tx) * 64;
+          return tx == 0 ? tr_frag2(in1[h] + rc, in1[h] + rc + 4 * 64) : tr_frag2(in1[h] + rc, in2[tx - 1][h] + rc);
+        } else return tr_frag(in_t + bo(j));
+      };
+      auto dy_frag = [&](int k) -> bf16x8 {
+        if constexpr (SWZ) { const int rc = ((k >> 1) * TW) * 64; return tr_frag2(dy1[k & 1] + rc, dy1[k & 1] + rc + 4 * 64); }
+        else return tr_frag(dy_t + ao(k));
+      };
       // input fragments run LA iterations (up to 3 MFMAs = 96 matrix cycles each) ahead of their use.  LA = 2 left the
       // reads ~190 cycles of lead, about one loaded-LDS round trip; W2_LA (default 4) doubles it for 8 VGPRs.
 #ifndef W2_LA
@@ -344,19 +448,19 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       constexpr int LA = W2_LA;
       bf16x8 aw[4][2];
       bf16x8 bq[LA + 1];
-      aw[0][0] = tr_frag(dy_t + ao(0));
-      aw[0][1] = tr_frag(dy_t + ao(1));
+      aw[0][0] = dy_frag(0);
+      aw[0][1] = dy_frag(1);
 #pragma unroll
-      for (int j = 0; j < LA; ++j) bq[j] = tr_frag(in_t + bo(j));
+      for (int j = 0; j < LA; ++j) bq[j] = in_frag(j);
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int hx = 0; hx < 6; ++hx) {
           const int j = i * 6 + hx, h = hx / 3, tx = hx % 3;
-          if (j + LA < NB) bq[(j + LA) % (LA + 1)] = tr_frag(in_t + bo(j + LA));
+          if (j + LA < NB) bq[(j + LA) % (LA + 1)] = in_frag(j + LA);
           if (hx == 0 && i + 1 < ROWS) {   // dY of the next output row, a whole input row ahead of its first use
-            aw[(i + 1) & 3][0] = tr_frag(dy_t + ao(2 * (i + 1)));
-            aw[(i + 1) & 3][1] = tr_frag(dy_t + ao(2 * (i + 1) + 1));
+            aw[(i + 1) & 3][0] = dy_frag(2 * (i + 1));
+            aw[(i + 1) & 3][1] = dy_frag(2 * (i + 1) + 1);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -34,7 +34,10 @@ def init_from_env(backend: str | None = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # bounded rendezvous: a rank that never arrives (died before init) must fail the others, not hang them
+        import datetime
+        tmo = float(os.environ.get("OCT_RDZV_TIMEOUT_S", "300"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=tmo))
     return rank, world, local
 
 
@@ -90,7 +93,10 @@ class GradAllReducer:
     def __init__(self, flat_grad: torch.Tensor, world: int | None = None, buckets=None, always_communicate=False):
         self.flat = flat_grad
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        self.stream = torch.cuda.Stream() if flat_grad.is_cuda else None
+        # highest priority: every compute kernel of the step is a persistent one-workgroup-per-CU launch, and a collective
+        # queued at default priority would have to wait for CUs behind whole conv kernels instead of slipping in between
+        # their workgroups
+        self.stream = torch.cuda.Stream(priority=-1) if flat_grad.is_cuda else None
         self.buckets = list(buckets) if buckets else [(0, 0, flat_grad.numel())]
         self.flush_stages = {b[0] for b in self.buckets}
         # a 1-rank group has nothing to exchange; `always_communicate` still issues the collectives (tests)
@@ -100,6 +106,11 @@ class GradAllReducer:
         self._by_stage = {b[0]: k for k, b in enumerate(self.buckets)}
         self._launched = [False] * len(self.buckets)
         self.launch_log = []        # (bucket index, lo, hi) in launch order, for tests / the bench line
+
+    def begin_step(self):
+        """Forget the launches of a step that never reached finish() (forward_backward raised after some stage hooks had
+        fired): without this the next step would skip those buckets and the ranks would fall out of step."""
+        self._launched = [False] * len(self.buckets)
 
     # ---- stage hook protocol (UNetEngine.backward) ----------------------------------------------------
     def stage_done(self, idx: int):
@@ -229,6 +240,7 @@ class DataParallelTrainer:
             loss = self._loss
         else:
             hook = self.reducer if (self.reducer.active and not self.use_graph) else None
+            self.reducer.begin_step()
             loss = self.model.forward_backward(x, target, self.w_ce, self.w_dice, stage_hook=hook)
             self._eager_steps += 1
         scale = self.reducer.finish()       # launches whatever backward did not, then joins the streams

@@ -276,12 +276,14 @@ class UNetEngine:
         return L.lib().oct_conv_stat_blocks(C.byref(d))
 
     def _wgrad(self, src: Src, dy, cout, taps, n, h, w, dy_mode=L.IN_PLAIN, dbias=None, fused_apply=None, kh=0, kw=0,
-               depth=0, in_shift=0, dy_img=(0, 0), dwp=None):
+               depth=0, in_shift=0, dy_img=(0, 0), dwp=None, partials_ok=True):
         """fused_apply = (y, coef, scale, shift): `dy` holds dA and the kernel applies BN backward on load.
         depth / in_shift / dy_img: one depth tap of a 3-D weight gradient (oct_hip.h, OctWgradDesc); dwp: write into this
-        (zeroed) slab instead of taking a new one."""
+        (zeroed) slab instead of taking a new one.  partials_ok: the caller unpacks through `_unpack` (OctUnpackJob.nparts
+        sums the per-workgroup slabs of deterministic mode); callers of the single-slab unpack entry points
+        (oct_unpack_wgrad_kk, oct_unpack_wgrad3d) pass False and stay on atomics."""
         ktot = src.channels
-        parts = 1 if (self.deterministic and dwp is None and depth == 0) else 0
+        parts = 1 if (self.deterministic and partials_ok and dwp is None and depth == 0) else 0
         d = L.WgradDesc(self.dt, n, h, w, src.c0, src.c1, cout, taps,
                         _xf(src.bn0), _xf(src.bn1), dy_mode, kh, kw, depth, in_shift,
                         dy_img[0], dy_img[1], parts)

@@ -253,7 +253,7 @@ class UNet3DEngine(UNetEngine):
                 bg.zero_()
             for kdi in (0, 1):
                 dwp = self._wgrad(Src(prev.y, cin_d, prev.bn), du, 4 * cout_d, 1, nl, hl, wl, dy_mode=L.IN_S2D, dbias=bg,
-                                  dy_img=(2, kdi))
+                                  dy_img=(2, kdi), partials_ok=False)
                 L.check(lib.oct_unpack_wgrad3d(L.PACK_DECONV3D_FPROP, dwp.data_ptr(), G[wkey].data_ptr(), cout_d, cin_d, kdi,
                                                int(accumulate), _stream()), "oct_unpack_wgrad3d")
             wp = self._pack(wkey, P[wkey], L.PACK_DECONV3D_DGRAD, cout_d, cin_d)

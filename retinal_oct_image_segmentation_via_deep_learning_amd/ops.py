@@ -68,6 +68,7 @@ def prepack(dtype: str, module: torch.nn.Module) -> None:
     """Refresh, in ONE launch, every packed copy an earlier step made of `module`'s weights and the optimizer has since
     outdated (fprop and dgrad order of ~45 convolutions = 87 five-microsecond launches per AttU_Net step otherwise).
     The per-op `packed()` calls of the step then all hit the cache."""
+    NBT_PENDING.clear()   # = drop_pending_counters(): every network forward starts here
     e = kernels(dtype)
     jobs, news = [], []
     for w in module.parameters():
@@ -94,8 +95,19 @@ def flush_counters() -> None:
     """num_batches_tracked += 1 for every train-mode BatchNorm op since the last call: ONE multi-tensor launch at the end of
     a block's / network's forward (every public forward ends in to_nchw) instead of one 5-us launch per layer."""
     if NBT_PENDING:
-        torch._foreach_add_(NBT_PENDING, 1)
+        # a BatchNorm applied twice since the last flush appears twice: ONE entry per tensor with its count (the multi-tensor
+        # kernel would otherwise read-modify-write the same address from two slots)
+        uniq = {}
+        for t in NBT_PENDING:
+            uniq.setdefault(id(t), [t, 0])[1] += 1
         NBT_PENDING.clear()
+        torch._foreach_add_([t for t, _ in uniq.values()], [c for _, c in uniq.values()])
+
+
+def drop_pending_counters() -> None:
+    """Start of a public forward: counters left behind by a forward that raised before its to_nchw must not be bumped by
+    this, unrelated, one."""
+    NBT_PENDING.clear()
 
 
 def _need_cuda(t: torch.Tensor):
@@ -351,7 +363,7 @@ class ConvAffineAct(torch.autograd.Function):
                                dbeta=None if dbeta is None else dbeta.clone())))
         src = Src(x0, c0, BNState(xf0[0], xf0[1], relu=xf0[2]) if xf0 else None,
                   x1, c1, BNState(xf1[0], xf1[1], relu=xf1[2]) if xf1 else None)
-        dwp = e._wgrad(src, dy, cout, taps, n, h, wd, dbias=dcb if fuse_bias else None, **kd)
+        dwp = e._wgrad(src, dy, cout, taps, n, h, wd, dbias=dcb if fuse_bias else None, partials_ok=not kk, **kd)
         dw = torch.empty_like(w)
         if kk:
             L.check(lib.oct_unpack_wgrad_kk(dwp.data_ptr(), dw.data_ptr(), cout, cin, kk[0], kk[1], 0, _stream()),

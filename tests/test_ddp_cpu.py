@@ -219,3 +219,28 @@ def test_bench_under_torchrun_contract_dry_run():
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["allreduce_ok"]
+
+
+def test_bench_eight_ranks_dry_run_gloo():
+    """The N = 8 case the driver runs on an 8-GPU node, rehearsed on CPU: eight self-spawned ranks, one JSON line that
+    states the backend and the world size the process group reports."""
+    import json
+    res = _run_bench(["--gpus", "8", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "1", "--features", "8"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world_size_seen"] == 8 and out["backend"] == "gloo"
+    assert out["allreduce_ok"] and out["params_identical_after_broadcast"] and out["config"]["parallelism"] == "dp8"
+
+
+def test_a_rank_that_dies_before_rendezvous_fails_the_launch_quickly():
+    """The parent terminates the surviving ranks (exactly the children it started) as soon as one exits non-zero; the
+    survivors' rendezvous itself is bounded by OCT_RDZV_TIMEOUT_S."""
+    import time
+    t0 = time.time()
+    res = _run_bench(["--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "1", "--warmup", "0", "--features", "8"],
+                     env={"OCT_BENCH_FAIL_RANK": "1", "OCT_RDZV_TIMEOUT_S": "30"})
+    assert res.returncode != 0 and time.time() - t0 < 90
+    assert "rank 1 exited with code 3" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

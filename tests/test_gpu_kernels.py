@@ -387,6 +387,96 @@ def test_head_forward_loss_and_dlogits(env, dt, cfg):
     close(host(dl2), O.softmax_bwd(pr, dpr.astype(np.float64)), dt, "dlogits (dprobs)", scale_tol=3e-5 if dt == "f32" else 1e-2)
 
 
+# (n, h, w, classes, w_dice, want_dlogits, explicit dprobs): which kernel takes it
+#   bf16 + classes <= 8 + labels + fused dW + no dlogits -> head_bwd_mfma_kernel (head_mfma.hip, the benchmarked one)
+#   everything else                                      -> head_bwd_fused_kernel (head.hip, vector form)
+HEAD_BWD_CASES = [(2, 16, 32, 8, 0.0, False, False), (1, 8, 64, 3, 0.6, False, False), (2, 8, 24, 2, 0.0, False, False),
+                  (1, 16, 32, 8, 0.5, True, False), (1, 8, 32, 16, 0.0, True, False), (2, 8, 32, 4, 0.0, False, True),
+                  (3, 5, 7, 8, 0.0, False, False)]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", HEAD_BWD_CASES)
+def test_head_backward_fused_matches_oracle(env, dt, cfg):
+    """oct_head_backward_fused -- both forms -- against oracle/ref_cpu.loss_head_* from the tensors the kernel reads
+    (teacher-forced: the stored y, the BN coefficients, the labels): dA, dW, db, the cross-entropy rows and the BN-backward
+    partial sums of the last block.  Round 2 checked the matrix-pipe form only against the vector form."""
+    L, E = env
+    n, h, w, ncls, w_dice, want_dl, use_dprobs = cfg
+    f = 32
+    rng = np.random.default_rng(hash(cfg) % 2**32 + 11)
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    edt = L.DT_F32 if dt == "f32" else L.DT_BF16
+    y = rnd(rng.standard_normal((n, f, h, w)), dt)
+    mean = y.mean(axis=(0, 2, 3)).astype(np.float32)
+    invstd = (1.0 / np.sqrt(y.var(axis=(0, 2, 3)) + 1e-5)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, f).astype(np.float32), (0.3 * rng.standard_normal(f)).astype(np.float32)
+    sc = (gamma * invstd).astype(np.float32)
+    sh = (beta - mean * sc).astype(np.float32)
+    wh = (rng.standard_normal((ncls, f)) / np.sqrt(f)).astype(np.float32)
+    bh = (0.1 * rng.standard_normal(ncls)).astype(np.float32)
+    tgt = rng.integers(0, ncls, (n, h, w))
+    yd, scd, shd, whd, bhd, md, ivd = dev(y, dt), fdev(sc), fdev(sh), fdev(wh), fdev(bh), fdev(mean), fdev(invstd)
+    tg = torch.from_numpy(tgt).cuda()
+    hd = L.HeadDesc(edt, n, h, w, f, ncls)
+    nb = lib.oct_head_blocks(C.byref(hd))
+    w_ce, eps = 0.7, 1e-7
+    # oracle forward on what the kernel reads
+    z = y.astype(np.float64) * sc[None, :, None, None] + sh[None, :, None, None]
+    a = np.maximum(z, 0)
+    rlog = np.einsum("bchw,oc->bohw", a, wh.astype(np.float64)) + bh[None, :, None, None]
+    rl, rce, rdice, cache = O.loss_head_fwd(rlog, tgt, w_ce, w_dice, eps)
+    dc = None
+    dprd = None
+    if use_dprobs:
+        dpr = rng.standard_normal((n, ncls, h, w)).astype(np.float32)
+        dprd = fdev(dpr)
+        rdl = O.softmax_bwd(cache[0], dpr.astype(np.float64))
+    else:
+        rdl = O.loss_head_bwd(cache, w_ce, w_dice, eps)
+        if w_dice:     # the Dice coefficients come from the forward head pass, as in a training step
+            part = torch.empty((nb, L.HEAD_LOSS_SLOTS), dtype=torch.float64, device="cuda")
+            probs = torch.empty((n, ncls, h, w), device="cuda")
+            L.check(lib.oct_head_forward(C.byref(hd), yd.data_ptr(), scd.data_ptr(), shd.data_ptr(), whd.data_ptr(),
+                                         bhd.data_ptr(), tg.data_ptr(), probs.data_ptr(), None, None, part.data_ptr(), st))
+            loss = torch.empty(3, device="cuda")
+            dc = torch.zeros(2 * L.MAX_CLASSES, device="cuda")
+            L.check(lib.oct_head_loss_finalize(C.byref(hd), part.data_ptr(), nb, w_ce, w_dice, eps, loss.data_ptr(), dc.data_ptr(), st))
+    fused_dw = ncls <= 8
+    dl = torch.full((n, h, w, ncls), float("nan"), dtype=tdt(dt), device="cuda") if (want_dl or not fused_dw) else None
+    da = torch.full((n, h, w, f), float("nan"), dtype=tdt(dt), device="cuda")
+    partials = torch.full((nb, 2, f), float("nan"), device="cuda")
+    db = torch.zeros(ncls, device="cuda")
+    dw = torch.zeros((ncls, f), device="cuda") if fused_dw else None
+    ce_rows = torch.full((nb, L.HEAD_LOSS_SLOTS), float("nan"), dtype=torch.float64, device="cuda") if not use_dprobs else None
+    L.check(lib.oct_head_backward_fused(
+        C.byref(hd), yd.data_ptr(), scd.data_ptr(), shd.data_ptr(), md.data_ptr(), ivd.data_ptr(), whd.data_ptr(), bhd.data_ptr(),
+        None if use_dprobs else tg.data_ptr(), L.ptr(dc), w_ce, L.ptr(dprd), L.ptr(dl), da.data_ptr(), partials.data_ptr(),
+        db.data_ptr(), L.ptr(dw), L.ptr(ce_rows), st), "oct_head_backward_fused")
+    torch.cuda.synchronize()
+    rda = np.einsum("bchw,cf->bfhw", rdl, wh.astype(np.float64))
+    tol = dict(scale_tol=3e-5) if dt == "f32" else {}
+    close(host(da), rda, dt, "dA = W^T dlogits (unmasked)", **tol)
+    if dl is not None:
+        close(host(dl), rdl, dt, "dlogits", scale_tol=3e-5 if dt == "f32" else 1e-2)
+    g = rda * (z > 0)
+    xhat = (y.astype(np.float64) - mean[None, :, None, None]) * invstd[None, :, None, None]
+    ps = partials.double().sum(0).cpu().numpy()
+    close(ps[0], g.sum(axis=(0, 2, 3)), dt, "BN-backward partial sums: sum g", scale_tol=1e-4 if dt == "f32" else 6e-3)
+    close(ps[1], (g * xhat).sum(axis=(0, 2, 3)), dt, "BN-backward partial sums: sum g*xhat", scale_tol=1e-4 if dt == "f32" else 6e-3)
+    close(db.cpu().numpy(), rdl.sum(axis=(0, 2, 3)), dt, "db", scale_tol=1e-4 if dt == "f32" else 6e-3)
+    if fused_dw:
+        close(dw.cpu().numpy(), np.einsum("bchw,bfhw->cf", rdl, a), dt, "dW", scale_tol=1e-4 if dt == "f32" else 6e-3)
+    if ce_rows is not None:
+        loss = torch.empty(3, device="cuda")
+        dc2 = torch.zeros(2 * L.MAX_CLASSES, device="cuda")
+        L.check(lib.oct_head_loss_finalize(C.byref(hd), ce_rows.data_ptr(), nb, 1.0, 0.0, eps, loss.data_ptr(), dc2.data_ptr(), st))
+        torch.cuda.synchronize()
+        ce = O.loss_head_fwd(rlog, tgt, 1.0, 0.0, eps)[1]
+        close(loss.cpu().numpy()[1:2], [ce], dt, "cross-entropy from the backward's loss rows", scale_tol=2e-5 if dt == "f32" else 2e-3)
+
+
 def test_layout_roundtrip_and_sgd(env):
     L, E = env
     lib = L.lib()

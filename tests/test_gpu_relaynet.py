@@ -160,3 +160,31 @@ def test_headline_width_7x3_convolution_matches_torch():
     rg = dict(ref.named_parameters())
     for k, p in m.named_parameters():
         close(p.grad.cpu().numpy(), rg[k].grad.numpy(), k, 5e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_deterministic_mode_matches_atomics_on_7x3_weight_gradients(golden_dir, dtype):
+    """engine.deterministic must not change a 7x3 weight gradient beyond summation order: its unpack entry point
+    (oct_unpack_wgrad_kk) reads ONE slab, so these launches stay on atomics (UNetEngine._wgrad, partials_ok)."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    z = np.load(os.path.join(golden_dir, "relay_encoder.npz"))
+    m = dropin("relay_encoder", dtype)
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}, strict=True)
+    m.cuda().train()
+    xs, extra = block_io(z)
+    e = ops.kernels(dtype)
+    keep = e.deterministic
+    grads = {}
+    try:
+        for det in (False, True):
+            e.deterministic = det
+            m.zero_grad(set_to_none=True)
+            out = m(*[x.cuda() for x in xs], *[t.cuda() for t in extra])
+            outs = out if isinstance(out, tuple) else (out,)
+            sum((o * torch.from_numpy(z[f"r{i}"]).cuda()).sum() for i, o in enumerate(outs) if o.dtype.is_floating_point).backward()
+            grads[det] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    finally:
+        e.deterministic = keep
+    for k in grads[False]:
+        a, b = grads[False][k].double(), grads[True][k].double()
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-6), k

@@ -242,3 +242,22 @@ def test_bf16_volumetric_unet_trains():
         opt.step()
     assert abs(losses[0] - rl) < 0.03 * rl, (losses[0], rl)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_deterministic_mode_matches_atomics_on_the_volumetric_network():
+    """engine.deterministic: the transposed 3-D convolutions unpack through oct_unpack_wgrad3d (one slab), so their weight
+    gradients must stay on atomics -- with per-workgroup partial slabs only the first strip's sum came back."""
+    model, ref, x, t = _case(5, 1, 16, 32, 32, 8, 3)
+    model.cuda().train()
+    grads = {}
+    keep = model._engine.deterministic
+    try:
+        for det in (False, True):
+            model._engine.deterministic = det
+            model.forward_backward(x.cuda(), t.cuda(), 1.0, 0.0)
+            grads[det] = {k: p.grad.clone() for k, p in model.named_parameters()}
+    finally:
+        model._engine.deterministic = keep
+    for k in grads[False]:
+        a, b = grads[False][k].double(), grads[True][k].double()
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-6), k
