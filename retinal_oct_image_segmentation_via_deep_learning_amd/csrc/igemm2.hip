@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       i_txi = t % p.tiles_x; t /= p.tiles_x;
       i_tyi = t % p.tiles_y; i_img = t / p.tiles_y;
     }
-    auto issue = [&](u32x4 (&Rr)[NSLOT], unsigned& vm) {
+    struct IssueSt { const unsigned char* hb; unsigned edge, cs2, safe; bool zok; };
+    auto issue_begin = [&]() -> IssueSt {
       const int ch = i_ch, txi = i_txi, tyi = i_tyi, img = i_img;
       if (i_sidx < last) {
         ++i_sidx;
@@ -338,15 +339,22 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // origin instead) + unsigned 32-bit lane offset: one global_load with an SGPR base per slot
       const unsigned cs2 = 2u * (unsigned)cs, safe = (unsigned)(HALO * (p.w + 1)) * cs2;
       const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - safe;
+      return IssueSt{hb, edge, cs2, safe, zok};
+    };
+    auto issue_slot = [&](const IssueSt& st, int i, u32x4& r, unsigned& vm) {
+      const bool ok = (!D3 || st.zok) && (code[i] & st.edge) == 0;
+      r = *reinterpret_cast<const u32x4*>(st.hb + (ok ? __umul24((unsigned)relp[i], st.cs2) : st.safe));
+      vm |= ok ? (1u << i) : 0u;
+    };
+    auto issue = [&](u32x4 (&Rr)[NSLOT], unsigned& vm) {
+      const IssueSt st = issue_begin();
       vm = 0;
 #pragma unroll
-      for (int i = 0; i < NSLOT; ++i) {
-        const bool ok = (!D3 || zok) && (code[i] & edge) == 0;
-        Rr[i] = *reinterpret_cast<const u32x4*>(hb + (ok ? __umul24((unsigned)relp[i], cs2) : safe));
-        vm |= ok ? (1u << i) : 0u;
-      }
+      for (int i = 0; i < NSLOT; ++i) issue_slot(st, i, Rr[i], vm);
     };
-    auto commit = [&](unsigned char* buf, const u32x4 (&Rr)[NSLOT], unsigned vm) {
+    struct CommitSt { float s[8], b[8]; float flo; bool xf; };
+    auto commit_begin = [&](bool always) -> CommitSt {
+      CommitSt st;
       const int ch = c_ch;
       if (c_sidx < last) { ++c_sidx; if (++c_ch == p.nch) c_ch = 0; }
       const int chc = (D3 && !s2d) ? ch % p.nchc : ch;   // channel chunk inside its depth tap
@@ -355,41 +363,46 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // wave-uniform on purpose (a 32-channel chunk lies in one source): a per-lane select between the
       // two kernel arguments would become a VECTOR load + s_waitcnt vmcnt(0) in the middle of the ring
       const bool first = s2d || chc * 32 < p.c0;
-      const bool xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
-      const float flo = xf_floor(first ? p.xf0 : p.xf1);   // wave-uniform: 0 (BN + ReLU) or -inf (plain affine)
-      float s[8], b[8];
-      if (xf) {
+      st.xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
+      st.flo = xf_floor(first ? p.xf0 : p.xf1);   // wave-uniform: 0 (BN + ReLU) or -inf (plain affine)
+      if (st.xf || always) {
         const int kx = s2d ? p.c0 : p.c0 + p.c1;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sxf + cg), s1 = *reinterpret_cast<const f32x4*>(sxf + cg + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(sxf + kx + cg), b1 = *reinterpret_cast<const f32x4*>(sxf + kx + cg + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[j] = s0[j]; s[4 + j] = s1[j]; b[j] = b0[j]; b[4 + j] = b1[j]; }
+        for (int j = 0; j < 4; ++j) { st.s[j] = s0[j]; st.s[4 + j] = s1[j]; st.b[j] = b0[j]; st.b[4 + j] = b1[j]; }
       }
-#pragma unroll
-      for (int i = 0; i < NSLOT; ++i) {
-        const int pix = pbase + 64 * i;
-        if (pix < NPIX) {
-          u32x4 v = Rr[i];
+      return st;
+    };
+    // always: the caller knows every source is transformed (branch-free form, used by the interleaved commit / issue loop)
+    auto commit_slot = [&](const CommitSt& st, unsigned char* buf, int i, const u32x4& r, unsigned vm, bool always) {
+      const int pix = pbase + 64 * i;
+      if (pix < NPIX) {
+        u32x4 v = r;
 #ifndef ABL_NO_XFORM
-          if (xf)
+        if (always || st.xf)
 #else
-          if (xf && p.n == 12345)
+        if (st.xf && p.n == 12345)
 #endif
-          {
+        {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float lo = fmaxf(fmaf(bf16lo(v[j]), s[2 * j], b[2 * j]), flo);
-              const float hi = fmaxf(fmaf(bf16hi(v[j]), s[2 * j + 1], b[2 * j + 1]), flo);
-              v[j] = pack_bf16x2(lo, hi);
-            }
+          for (int j = 0; j < 4; ++j) {
+            const float lo = fmaxf(fmaf(bf16lo(v[j]), st.s[2 * j], st.b[2 * j]), st.flo);
+            const float hi = fmaxf(fmaf(bf16hi(v[j]), st.s[2 * j + 1], st.b[2 * j + 1]), st.flo);
+            v[j] = pack_bf16x2(lo, hi);
           }
-          // out-of-image pixels are exactly zero (padding applies to the activated tensor)
-          const bool live = (vm & (1u << i)) != 0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = live ? v[j] : 0u;
-          *reinterpret_cast<u32x4*>(buf + pix * PIXB + grp * 16) = v;
         }
+        // out-of-image pixels are exactly zero (padding applies to the activated tensor)
+        const bool live = (vm & (1u << i)) != 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = live ? v[j] : 0u;
+        *reinterpret_cast<u32x4*>(buf + pix * PIXB + grp * 16) = v;
       }
+    };
+    auto commit = [&](unsigned char* buf, const u32x4 (&Rr)[NSLOT], unsigned vm) {
+      const CommitSt st = commit_begin(false);
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) commit_slot(st, buf, i, Rr[i], vm, false);
     };
 #pragma unroll
     for (int j = 0; j < D; ++j) issue(R[j], vmask[j]);   // stages past the end re-read the last one
@@ -401,6 +414,40 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     // branch-free (the stage count is padded to a multiple of D, both roles run the padded count,
     // indices clamp to the last stage): with branches around the loads hipcc protects the ring
     // registers with s_waitcnt vmcnt(0) and the prefetch collapses.
+#ifndef IG2_PSPREAD
+#define IG2_PSPREAD 1
+#endif
+    // SPREAD (3x3 kernels whose sources are all transformed on load): slot i of the next stage is committed and IMMEDIATELY
+    // re-issued for the stage after next, so the stage's global loads leave one by one over the ~3.7 k cycles of commit work
+    // instead of as one burst behind it.  Why: the MFMA waves stream their weights from L2 through the same per-CU
+    // load path, and while a burst of HBM-missing tile loads sat in it the weight loads' latency exceeded the ring's lead
+    // (profiles/r03_ig2_traces.txt: stages that coincide with a new tile's loads ran 30-60 % longer).
+    const bool spread = IG2_PSPREAD && TAPS == 9 && !D3 && p.xf0 != 0 && (p.c1 == 0 || p.xf1 != 0);
+    if (spread) {
+      for (int s0 = 0; s0 < nstage_pad; s0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const int nx = s0 + j + 1;
+          if (wave == 4) TRACE(4, nx - 1);
+          unsigned char* const buf = buf0 + (nx & 1) * BUFB;
+          const CommitSt cst = commit_begin(true);
+          const IssueSt ist = issue_begin();
+          const unsigned vold = vmask[(j + 1) % D];
+          unsigned vnew = 0;
+#pragma unroll
+          for (int i = 0; i < NSLOT; ++i) {
+            commit_slot(cst, buf, i, R[(j + 1) % D][i], vold, true);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_slot(ist, i, R[(j + 1) % D][i], vnew);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          vmask[(j + 1) % D] = vnew;
+          if (wave == 4) TRACE(6, nx - 1);
+          __syncthreads();
+          if (wave == 4) TRACE(7, nx - 1);
+        }
+      }
+    } else
     for (int s0 = 0; s0 < nstage_pad; s0 += D) {
 #pragma unroll
       for (int j = 0; j < D; ++j) {
@@ -451,7 +498,17 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // M16: weights of two taps.  Tap t sits in slot t & 1 and tap t + 1 is fetched while it multiplies; a stage has nine taps,
   // so the next stage's tap 0 lands in slot 1 and is moved to slot 0 when that stage starts (16 v_mov per stage; a third
   // slot instead cost 16 more registers and spilled the 128-channel kernels)
-  Frag a16[M16 ? 2 : 1][M16 ? 2 * NF : 1];
+#ifndef IG2_WRING3
+#define IG2_WRING3 1
+#endif
+  // WR3: three weight slots, tap t in slot t % 3, tap t + 2 fetched while tap t multiplies (two taps = ~1000 matrix cycles
+  // of lead; nine taps per stage, so the slots line up across stages and nothing has to be moved).  With two slots the
+  // lead was ONE tap (~500 cycles), less than an L2 hit takes while the producers' loads of a new tile miss to HBM: the
+  // stages that coincide with those loads ran 30-60 % longer (in-kernel timeline, profiles/r03_ig2_traces.txt: MFMA phase
+  // 5.5 k cycles on even stages, 7.3-9.3 k on odd ones).
+  constexpr bool WR3 = IG2_WRING3 && M16;
+  constexpr int NWS = WR3 ? 3 : 2;
+  Frag a16[M16 ? NWS : 1][M16 ? 2 * NF : 1];
   f32x16 acc[MF][NF];
   float s1[STATS ? NF : 1][16], s2[STATS ? NF : 1][16];  // BN partial sums (lane = pixel column)
   if (STATS) {
@@ -555,7 +612,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     }
   };
 #ifndef IG2_PERM_EPI
-#define IG2_PERM_EPI 1
+#define IG2_PERM_EPI 0   /* measured (r3, same box, two runs): +1...+6 % on every 16x16x32 launch -- 32-B store segments instead of 64-B ones */
 #endif
   // 16x16x32 accumulators leave WITHOUT the LDS transpose: lane (r16, kg) holds, per channel half cc, channels 16cc + 4kg ..+3
   // of pixel r16 (quarter half 0) and of pixel 16 + r16 (half 1) -- v_permlane16_swap trades the half-1 piece of the even kg
@@ -691,15 +748,18 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     {
       const unsigned char* tb = buf0 + cur * BUFB;
       const bf16_t* wbase = nullptr; const bf16_t* wbase_n = nullptr;
+      const bf16_t* wuni = nullptr; const bf16_t* wuni_n = nullptr;   // the same without the lane term (wave-uniform)
       const size_t qstride = (size_t)TAPS * p.nk16 * 512, tstride = (size_t)p.nk16 * 512;
       if (!WRES) {
         const int nb0 = nbi * (NT / 32) + wn * NF;
         wbase = p.wp + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512 + lane * 8;
+        if constexpr (M16 && !STATS) wuni = p.wp + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512;
         int n_ch = ch + 1, n_item = item;
         if (n_ch == p.nch) { n_ch = 0; n_item = item + 1; }
         if (n_item >= nitems_wg) { n_item = item; n_ch = ch; }  // last stage: harmless re-read of valid memory
         const int n_nbi = n_item == item ? nbi : (nbi + 1 == p.nblk ? 0 : nbi + 1);
         wbase_n = p.wp + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512 + lane * 8;
+        if constexpr (M16 && !STATS) wuni_n = p.wp + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512;
         if (sidx == 0 && !M16) {
 #pragma unroll
           for (int j = 0; j < PF; ++j)
@@ -718,48 +778,68 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // DMA tiles (dense, swizzled): the chunk position depends on the tile column r + tx, so each (tx, k16) has its own
       // lane base; the row (m + ty) stays a compile-time offset
       constexpr int NTX = (TAPS == 9) ? 3 : 1;
-      const unsigned char* lbs[DMA ? NTX : 1][2];
+      unsigned lbs[DMA ? NTX : 1][2];   // byte offsets from smem (32-bit: six 64-bit pointers cost the dgrad kernels their last registers)
       if constexpr (DMA && !M16) {
 #pragma unroll
         for (int tx = 0; tx < NTX; ++tx)
 #pragma unroll
           for (int k16 = 0; k16 < 2; ++k16) {
             const int col = r + tx;
-            lbs[tx][k16] = tb + ((wm * MF) * LW + col) * 64 + (((2 * k16 + hh) ^ ((col >> 2) & 3)) * 16);
+            lbs[tx][k16] = (unsigned)(cur * BUFB + ((wm * MF) * LW + col) * 64 + (((2 * k16 + hh) ^ ((col >> 2) & 3)) * 16));
           }
       }
       auto xptr = [&](int s, int m) -> const unsigned char* {
         if constexpr (DMA) {
           const int tap = s >> 1, k16 = s & 1;
           const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
-          return lbs[tx][k16] + (m + ty) * LW * 64;
+          return smem + (lbs[tx][k16] + (unsigned)((m + ty) * LW * 64));
         } else return lb + xoff(s, m);
       };
       if constexpr (M16) {
         const int r16 = lane & 15, kg = lane >> 4;
         const unsigned char* lb16 = tb + ((wm * MF) * LW + r16) * PIXB + kg * 16;
         auto boff = [](int u, int m) constexpr { const int t = u >> 1; return ((m + t / 3) * LW + t % 3 + 16 * (u & 1)) * PIXB; };
-        const unsigned char* lbs16[DMA ? 3 : 1][2];   // DMA tiles: lane base per (tap column, pixel half), key = (col >> 1) & 3
-        if constexpr (DMA) {
+        unsigned lbs16[DMA ? 3 : 1];   // DMA tiles: lane byte offset per tap column; key = (col >> 1) & 3 is the same for both pixel
+        if constexpr (DMA) {           // halves (col + 16), so the half is a compile-time +16 pixels
 #pragma unroll
-          for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-              const int col = r16 + 16 * hf + tx;
-              lbs16[tx][hf] = tb + ((wm * MF) * LW + col) * 64 + ((kg ^ ((col >> 1) & 3)) * 16);
-            }
+          for (int tx = 0; tx < 3; ++tx) {
+            const int col = r16 + tx;
+            lbs16[tx] = (unsigned)(cur * BUFB + ((wm * MF) * LW + col) * 64 + ((kg ^ ((col >> 1) & 3)) * 16));
+          }
         }
         auto bptr = [&](int u, int m) -> const unsigned char* {
-          if constexpr (DMA) { const int t = u >> 1; return lbs16[t % 3][u & 1] + (m + t / 3) * LW * 64; }
+          if constexpr (DMA) { const int t = u >> 1; return smem + (lbs16[t % 3] + (unsigned)(((m + t / 3) * LW + 16 * (u & 1)) * 64)); }
           else return lb16 + boff(u, m);
         };
-        // this lane's 16 B of a weight fragment pair: rows 16*cc + r16 of k16 fragment kg>>1, k half kg&1 (32x32x16 order)
+        // this lane's 16 B of a weight fragment pair: rows 16*cc + r16 of k16 fragment kg>>1, k half kg&1 (32x32x16 order).
+        // Addressed as a wave-uniform 64-bit base (stage, channel fragment, tap: SGPRs) + ONE 32-bit lane offset, so that every
+        // weight load is `global_load_dwordx4 v, v_off, s[base]`: per-fragment 64-bit VGPR pointers cost 16 registers here and
+        // pushed the three-slot ring into scratch.
+        const unsigned wlane = (unsigned)(((kg >> 1) * 512 + ((kg & 1) * 32 + r16) * 8) * 2);
+        const unsigned char* const wu = reinterpret_cast<const unsigned char*>(wuni);
+        const unsigned char* const wun = reinterpret_cast<const unsigned char*>(wuni_n);
+        // (register allocation decides which form fits: with BatchNorm sums in the kernel the per-lane pointer form stays
+        //  under 240 registers and the scalar-base form spills three dwords; without them it is the other way round)
+        constexpr bool WSB = !STATS;
         const int lpart = (kg >> 1) * 512 + ((kg & 1) * 32 + r16) * 8 - lane * 8;   // wbase / wbase_n carry lane*8
         auto aoff = [&](int c) { return (size_t)(c >> 1) * qstride + (c & 1) * 128 + lpart; };
+        auto wfrag = [&](bool next, int c, int tt) {
+          if constexpr (WSB) {
+            const size_t off = ((size_t)(c >> 1) * qstride + (size_t)tt * tstride) * 2 + (c & 1) * 256;
+            return M::load((next ? wun : wu) + off + (size_t)wlane);
+          } else {
+            const bf16_t* wb = next ? wbase_n : wbase;
+            return M::load(wb + aoff(c) + tt * tstride);
+          }
+        };
         if (sidx == 0) {
 #pragma unroll
-          for (int c = 0; c < 2 * NF; ++c) a16[0][c] = M::load(wbase + aoff(c));
-        } else {
+          for (int c = 0; c < 2 * NF; ++c) a16[0][c] = wfrag(false, c, 0);
+          if constexpr (WR3) {
+#pragma unroll
+            for (int c = 0; c < 2 * NF; ++c) a16[1][c] = wfrag(false, c, 1);
+          }
+        } else if constexpr (!WR3) {
 #pragma unroll
           for (int c = 0; c < 2 * NF; ++c) a16[0][c] = a16[1][c];   // fetched under the previous stage's last tap
         }
@@ -774,12 +854,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
             for (int m = 0; m < MF; ++m) b16[(s + 1) & 1][m] = M::load(bptr(s + 1, m));
           }
 #ifndef ABL_NO_WLOAD
-          if ((s & 1) == 0) {   // weights of tap t + 1 (the next stage's tap 0 under this one's last)
-            const int t2 = t + 1;
-            const bf16_t* wb = t2 < TAPS ? wbase : wbase_n;
-            const int tt = t2 < TAPS ? t2 : 0;
+          if ((s & 1) == 0) {   // weights of tap t + 1 (WR3: t + 2); the next stage's first tap(s) under this one's last
+            const int t2 = t + (WR3 ? 2 : 1);
+            const int tt = t2 < TAPS ? t2 : t2 - TAPS;
 #pragma unroll
-            for (int c = 0; c < 2 * NF; ++c) a16[t2 & 1][c] = M::load(wb + aoff(c) + tt * tstride);
+            for (int c = 0; c < 2 * NF; ++c) a16[WR3 ? t2 % 3 : (t2 & 1)][c] = wfrag(t2 >= TAPS, c, tt);
           }
 #endif
           __builtin_amdgcn_sched_barrier(0);
@@ -787,8 +866,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           for (int m = 0; m < MF; ++m)
 #pragma unroll
             for (int c = 0; c < 2 * NF; ++c) {
-              if (s & 1) { if (c & 1) M::template mma16<3>(acc[m][c >> 1], a16[t & 1][c], b16[s & 1][m]); else M::template mma16<2>(acc[m][c >> 1], a16[t & 1][c], b16[s & 1][m]); }
-              else { if (c & 1) M::template mma16<1>(acc[m][c >> 1], a16[t & 1][c], b16[s & 1][m]); else M::template mma16<0>(acc[m][c >> 1], a16[t & 1][c], b16[s & 1][m]); }
+              const Frag& wf = a16[WR3 ? t % 3 : (t & 1)][c];
+              if (s & 1) { if (c & 1) M::template mma16<3>(acc[m][c >> 1], wf, b16[s & 1][m]); else M::template mma16<2>(acc[m][c >> 1], wf, b16[s & 1][m]); }
+              else { if (c & 1) M::template mma16<1>(acc[m][c >> 1], wf, b16[s & 1][m]); else M::template mma16<0>(acc[m][c >> 1], wf, b16[s & 1][m]); }
             }
           if (DEFER && s >= 1 && (s - 1) % ESTRIDE == 0 && (s - 1) / ESTRIDE < NFR) {
             if (pend) store_frag(((s - 1) / ESTRIDE) / NF, ((s - 1) / ESTRIDE) % NF);

@@ -116,6 +116,7 @@ class BNState:
     mean: torch.Tensor | None = None
     invstd: torch.Tensor | None = None
     relu: bool = True   # False: the consumer applies scale*x + shift without the ReLU (OCT_XF_AFFINE: a deferred bias add)
+    frozen: bool = False   # eval-mode forward: mean / invstd are the RUNNING statistics; backward is a per-channel affine
 
 
 def _xf(bn) -> int:
@@ -165,6 +166,7 @@ class UNetEngine:
         self._arena, self._arena_on, self._arena_off, self._arena_short = None, False, 0, False
         self._unpack_jobs = []
         self._nbt = []
+        self._frozen_bwd = False
         self._consts = {}  # (value, n, device) -> constant fp32 vector (never written)
         # OCT_ROWDOT=0: one-output-channel 1x1 convolutions stay on the padded MFMA kernels (A/B switch, parity tests)
         self.rowdot_off = os.environ.get("OCT_ROWDOT", "1") == "0"
@@ -377,7 +379,14 @@ class UNetEngine:
                 cout, P[nk + ".weight"].data_ptr(), P[nk + ".bias"].data_ptr(),
                 P[nk + ".running_mean"].data_ptr(), P[nk + ".running_var"].data_ptr(), BN_EPS,
                 scale.data_ptr(), shift.data_ptr(), cbias, _stream()), "oct_bn_eval_coeffs")
-            bn = BNState(scale, shift)
+            if self._frozen_bwd:
+                # backward through frozen statistics (fine-tuning with model.eval()): xhat = (y + conv_bias - running_mean)
+                # * rsqrt(running_var + eps) for d(gamma); the data gradient is dz * gamma * invstd, no statistics terms
+                invstd = torch.rsqrt(P[nk + ".running_var"] + BN_EPS)
+                mean = P[nk + ".running_mean"] - P[keys.b] if keys.b else P[nk + ".running_mean"]
+                bn = BNState(scale, shift, mean, invstd, frozen=True)
+            else:
+                bn = BNState(scale, shift)
         return ConvRec(wkey, nk + ".weight", nk + ".bias", keys.b, src, y, bn, cout, n, h, w)
 
     def _block(self, P, blk: BlockSpec, src, n, h, w, train, ctx):
@@ -387,7 +396,8 @@ class UNetEngine:
         return r2
 
     def forward(self, P: dict, x: torch.Tensor, train: bool, target: torch.Tensor | None = None,
-                loss_cfg=(1.0, 0.0, 1e-7), want_probs=True, want_argmax=False, want_logits=False, defer_loss=False):
+                loss_cfg=(1.0, 0.0, 1e-7), want_probs=True, want_argmax=False, want_logits=False, defer_loss=False,
+                frozen_bwd=False):
         """P: name -> fp32 device tensor with the reference's state_dict keys.
         Returns (ctx, probs|None, argmax|None, logits|None).
         defer_loss: the caller will run backward() right away and wants no output but the loss; when the
@@ -407,8 +417,9 @@ class UNetEngine:
         if dev.type != "cuda":
             raise L.OctError("the HIP path needs a device tensor (there is no CPU fallback)")
         xf = x.detach().to(torch.float32).contiguous()
-        if train:
+        if train or frozen_bwd:
             self._prepack(P)
+        self._frozen_bwd = bool(frozen_bwd) and not train
         ctx = Ctx(n=n, h=h, w=w, loss_cfg=tuple(loss_cfg))
         self._nbt = []
         xt = self._act(n, h, w, self.cin, dev)
@@ -446,6 +457,7 @@ class UNetEngine:
         if self._nbt:       # BatchNorm step counters: one multi-tensor launch instead of one per layer
             torch._foreach_add_(self._nbt, 1)
             self._nbt = []
+        self._frozen_bwd = False
         hd = L.HeadDesc(self.dt, n, h, w, self.f, self.ncls)
         probs = torch.empty((n, self.ncls, h, w), dtype=torch.float32, device=dev) if want_probs else None
         amax = torch.empty((n, h, w), dtype=torch.int64, device=dev) if want_argmax else None
@@ -507,6 +519,13 @@ class UNetEngine:
                 "oct_bn_bwd_finalize")
         if self.debug is not None:
             self.debug["g:" + rec.wkey] = g.float().clone()
+        if rec.bn.frozen:
+            # running statistics do not depend on the batch: dy = k0 * dz (k0 = gamma * invstd), and a convolution bias in
+            # front of the BatchNorm gets d(bias) = sum dy = k0 * sum dz
+            coef[1:].zero_()
+            if rec.cbkey:
+                gb = coef[0] * partials[:, 0, :].sum(0)
+                G[rec.cbkey].add_(gb) if accumulate else G[rec.cbkey].copy_(gb)
         if defer_apply and not pooled:
             return g, coef   # the consumer (first-layer wgrad) applies dy = k0*mask*dA + k1*y + k2 on load
         if pool_fused:
@@ -550,7 +569,7 @@ class UNetEngine:
     def _block_backward(self, name, da, dpool, G, accumulate, need_dx=True, partials=None):
         r1, r2 = self._ctx.convs[name]
         for r in (r1, r2):
-            if r.cbkey and not accumulate:
+            if r.cbkey and not accumulate and not r.bn.frozen:
                 G[r.cbkey].zero_()   # a bias in front of a train-mode BatchNorm cancels in (y - mean): zero gradient
         dy2 = self._bn_backward(r2, da, dpool, G, accumulate, partials=partials)
         da1, _ = self._conv_backward(r2, dy2, G, accumulate)

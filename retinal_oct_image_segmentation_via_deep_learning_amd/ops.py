@@ -247,6 +247,10 @@ class ConvAffineAct(torch.autograd.Function):
                                                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_EPS,
                                                scale.data_ptr(), shift.data_ptr(), L.ptr(cbias), _stream()),
                         "oct_bn_eval_coeffs")
+                if any(ctx.needs_input_grad):
+                    # frozen statistics under autograd: backward needs xhat = (y + conv_bias - running_mean) * invstd for d(gamma)
+                    invstd = torch.rsqrt(bn.running_var + BN_EPS)
+                    mean = bn.running_mean - cbias.detach() if cbias is not None else bn.running_mean.clone()
             else:   # bare convolution (+ bias): constants instead of three tiny fill / copy launches per op
                 scale = e._const(1.0, cout, dev)
                 shift = cbias.detach() if cbias is not None else e._const(0.0, cout, dev)
@@ -290,8 +294,8 @@ class ConvAffineAct(torch.autograd.Function):
         npix = n * h * wd
         dev = x0.device
         dout = dout.contiguous()
-        if bn is not None and not train_bn:
-            raise NotImplementedError("backward through an eval-mode BatchNorm is not on the HIP path")
+        if bn is not None and not train_bn and mean is None:
+            raise RuntimeError("backward through an eval-mode BatchNorm whose forward ran under no_grad()")
         if lazy == "relu":
             dz = dout       # dA: the mask [scale*y + shift > 0] is applied inside the two BN-backward passes
         elif act == L.ACT_PRELU:
@@ -325,6 +329,8 @@ class ConvAffineAct(torch.autograd.Function):
             L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, cout, float(npix), gamma.data_ptr(),
                                             mean.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                             coef.data_ptr(), 0, _stream()), "oct_bn_bwd_finalize")
+            if not train_bn:   # frozen (eval-mode) BatchNorm: a per-channel affine -- dy = k0 * dz, no statistics terms
+                coef[1:].zero_()
             # dz stays intact when somebody else still reads it (the residual branch's gradient, autograd's own buffer)
             dy = torch.empty_like(dz) if (has_res or dz is dout) else dz
             L.check(lib.oct_bn_bwd_apply_to(e.dt, dy.data_ptr(), dz.data_ptr(), y.data_ptr(), coef.data_ptr(),
@@ -332,7 +338,8 @@ class ConvAffineAct(torch.autograd.Function):
                                             shift.data_ptr() if lazy == "relu" else None,
                                             npix, cout, _stream()), "oct_bn_bwd_apply_to")
             if has_bias:
-                dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
+                # train mode: a bias in front of BatchNorm cancels in (y - mean); frozen statistics: d(bias) = sum dy = k0 * sum dz
+                dcb = torch.zeros(cout, dtype=torch.float32, device=dev) if train_bn else coef[0] * partials[:, 0, :].sum(0)
         else:
             dy = dz
             if has_bias and cin % 32 == 0 and not ctx.rowdot:

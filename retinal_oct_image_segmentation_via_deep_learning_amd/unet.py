@@ -34,7 +34,9 @@ class _UNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, *params):
-        out = model._run(x, train=True, keep_ctx=ctx)
+        # eval() mode under autograd: BatchNorm on its running statistics, differentiated as the per-channel affine it then is
+        # (frozen-BN fine-tuning, as the reference nn.Module allows -- YNet_2022.py:548-569)
+        out = model._run(x, train=model.training, keep_ctx=ctx, frozen_bwd=not model.training)
         ctx.model = model
         return out
 
@@ -55,30 +57,15 @@ class _UNetFn(torch.autograd.Function):
         return (None, None) + tuple(G[n] for n in names)
 
 
-class _EvalNoGradFn(torch.autograd.Function):
-    """eval()-mode forward under autograd: the output keeps a grad_fn, so a fine-tuning script that calls
-    .backward() through frozen BatchNorm statistics gets THIS message instead of torch's "element 0 of tensors
-    does not require grad" (the reference nn.Module would differentiate through running statistics)."""
-
-    @staticmethod
-    def forward(ctx, out, *params):
-        return out.view_as(out)
-
-    @staticmethod
-    def backward(ctx, dout):
-        raise NotImplementedError("backward through an eval()-mode forward (BatchNorm on running statistics) is not "
-                                  "implemented on the HIP path: call model.train() for training steps")
-
-
 class _EngineNet(nn.Module):
     """Shared host logic of the engine-backed networks; subclasses build the parameter containers
     (in the reference's construction order) and set `self._engine`."""
 
-    def _run(self, x, train: bool, keep_ctx=None):
+    def _run(self, x, train: bool, keep_ctx=None, frozen_bwd=False):
         """The reference forward's return value: probabilities (YNet_2022 UNet) or logits (BioNet UNet)."""
         soft = self._engine.spec.softmax_out
         ectx, probs, _, lg = self._engine.forward(self._tensors(), x, train=train, want_probs=soft,
-                                                  want_logits=not soft)
+                                                  want_logits=not soft, frozen_bwd=frozen_bwd)
         if keep_ctx is not None:
             keep_ctx.ectx = ectx
         return probs if soft else lg
@@ -108,12 +95,9 @@ class _EngineNet(nn.Module):
             # the reference nn.Module returns d(out)/d(x); the engine stops at the first layer's weights
             raise NotImplementedError("gradients with respect to the network INPUT are not implemented on the HIP "
                                       "path (x.requires_grad=True); detach the input")
-        if grad_on and self.training:
-            return _UNetFn.apply(self, x, *self.parameters())
-        out = self._run(x, train=self.training)
         if grad_on:
-            return _EvalNoGradFn.apply(out, *self.parameters())
-        return out
+            return _UNetFn.apply(self, x, *self.parameters())
+        return self._run(x, train=self.training)
 
     # ---- fused extras (not in the reference) --------------------------------------
     @torch.no_grad()

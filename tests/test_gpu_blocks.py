@@ -242,3 +242,35 @@ def test_deferred_activation_schedule_is_bit_identical_to_the_materialised_one(d
     bad = [k for k in res[True] if not (torch.allclose(res[True][k], res[False][k], rtol=1e-4, atol=1e-7)
                                         if k in loose else torch.equal(res[True][k], res[False][k]))]
     assert bad == [], bad
+
+
+@pytest.mark.parametrize("name", list(BLOCKS))
+def test_f32_block_backward_through_frozen_batchnorm_matches_torch(golden_dir, name):
+    """eval() + backward (frozen-BN fine-tuning): BatchNorm on running statistics is a per-channel affine; every gradient,
+    conv biases in front of the BatchNorm included, against the stock-torch restatement (oracle/torch_blocks.py, pinned to
+    the reference's fixtures by tests/test_oracle_blocks.py) in float64."""
+    from oracle import torch_blocks as TB
+    z, m, xs = load_block(golden_dir, name, Dropins)
+    _, ref, _ = load_block(golden_dir, name, TB)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for a, b in zip(m.modules(), ref.modules()):
+            if isinstance(a, torch.nn.BatchNorm2d):
+                a.running_mean.copy_(0.3 * torch.randn(a.running_mean.shape, generator=g))
+                a.running_var.copy_(0.5 + torch.rand(a.running_var.shape, generator=g))
+                b.running_mean.copy_(a.running_mean)
+                b.running_var.copy_(a.running_var)
+    m.set_compute_dtype("f32").cuda().eval()
+    ref = ref.double().eval()
+    xd = [x.cuda().requires_grad_(True) for x in xs]
+    xr = [x.double().requires_grad_(True) for x in xs]
+    out, rout = m(*xd), ref(*xr)
+    close(out.detach().cpu().numpy(), rout.detach().numpy(), "out", 2e-5, 1.0)
+    r = torch.from_numpy(z["r"])
+    (out * r.cuda()).sum().backward()
+    (rout * r.double()).sum().backward()
+    for i, (a, b) in enumerate(zip(xd, xr)):
+        close(a.grad.cpu().numpy(), b.grad.numpy(), f"gx{i}", 2e-3)
+    rg = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        close(p.grad.cpu().numpy(), rg[k].grad.numpy(), k, 2e-3)

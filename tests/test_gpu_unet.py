@@ -358,16 +358,60 @@ def _tiny(dtype="f32", f=8, c=3):
     return UNet(1, c, init_features=f, compute_dtype=dtype).cuda()
 
 
-def test_eval_mode_backward_and_input_gradients_raise_clearly():
-    model = _tiny().eval()
-    x = torch.randn(1, 1, 32, 32, device="cuda")
-    out = model(x)                              # inference without no_grad() keeps working ...
-    assert out.grad_fn is not None
-    with pytest.raises(NotImplementedError, match="eval"):
-        out.sum().backward()                    # ... and differentiating it names the reason
+def _randomise_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
-        assert model(x).grad_fn is None
-    model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1.0 + 0.3 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.3 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+
+
+@pytest.mark.parametrize("net", ["ynet", "bionet"])
+def test_frozen_batchnorm_fine_tune_backward_matches_torch_oracle(net):
+    """model.eval() + .backward(): BatchNorm on its running statistics is a per-channel affine -- every parameter gradient
+    (conv biases in front of a frozen BatchNorm included: no longer zero) against stock torch.nn in float64, the arithmetic
+    the reference nn.Module (YNet_2022.py:548-569, BioNet_2020.py:24-75) runs on; buffers stay untouched."""
+    from oracle import torch_unet
+    torch.manual_seed(21)
+    if net == "ynet":
+        from retinal_oct_image_segmentation_via_deep_learning_amd import UNet
+        model = UNet(1, 3, init_features=8, compute_dtype="f32")
+        ref = torch_unet.TorchUNet(1, 3, 8)
+        x = torch.randn(2, 1, 32, 48)
+    else:
+        from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment.BioNet_2020 import UNet as BioUNet
+        model = BioUNet(1, 2, compute_dtype="f32")
+        ref = torch_unet.TorchBioUNet(1, 2)
+        x = torch.randn(1, 1, 16, 24)
+    _randomise_bn(model, 5)
+    ref.load_state_dict(model.state_dict())
+    ref = ref.double().eval()
+    model = model.cuda().eval()
+    buffers = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    out = model(x.cuda())
+    assert out.grad_fn is not None
+    r = torch.randn(out.shape, generator=torch.Generator().manual_seed(9))
+    (out * r.cuda()).sum().backward()
+    rout = ref(x.double())
+    (rout * r.double()).sum().backward()
+    assert float((out.detach().cpu().double() - rout.detach()).abs().max()) < 2e-5 * max(1.0, float(rout.abs().max()))
+    rg = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        e = float((p.grad.cpu().double() - rg[k].grad).abs().max())
+        assert e <= 2e-3 * max(float(rg[k].grad.abs().max()), 1e-4), (k, e)
+    for k, v in model.state_dict().items():
+        if k in buffers:
+            assert torch.equal(v, buffers[k]), k        # eval mode: no statistics update, no step count
+    with torch.no_grad():
+        assert model(x.cuda()).grad_fn is None
+
+
+def test_input_gradients_raise_clearly_and_second_backward_too():
+    model = _tiny().train()
+    x = torch.randn(1, 1, 32, 32, device="cuda")
     with pytest.raises(NotImplementedError, match="INPUT"):
         model(x.clone().requires_grad_(True))
     out = model(x)
