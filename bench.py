@@ -110,11 +110,13 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercise the multi-rank plumbing on CPU tensors")
     ap.add_argument("--bucket-mb", type=float, default=3.0, help="gradient bucket threshold (MB)")
-    ap.add_argument("--config", default="cfg2", choices=("cfg2", "cfg1", "cfg4", "cfg5"),
+    ap.add_argument("--config", default="cfg2", choices=("cfg2", "cfg1", "cfg4", "cfg5", "relaynet", "mgunet2"),
                     help="cfg2 (default, the headline line the driver runs): Layers_Segment UNet(1,8) 512x1024 batch 32; "
                          "cfg1: BioNet_2020.UNet(1,2) 256x256 batch 4 (add --graph: one hipGraph replay per step); "
                          "cfg4: attention-gated AttU_Net(1,3) 496x768 batch 16; cfg5: volumetric UNet3D 64x512x512 batch 4 "
-                         "(BASELINE configs[0] / [3] / [4]; single GPU; --batch/--height/--width/--depth shrink them)")
+                         "(BASELINE configs[0] / [3] / [4]; single GPU; --batch/--height/--width/--depth shrink them); "
+                         "relaynet: ReLayNet_2017.ReLayNet(1,10) 496x768 batch 16; mgunet2: MGUNet_2021.MGUNet_2(1,11) 496x768 "
+                         "batch 16 (SURVEY 8(f) block families: throughput evidence)")
     ap.add_argument("--depth", type=int, default=64, help="cfg5: slices per volume")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+loss+backward as one HIP graph (no gain at batch 32: the queue never runs dry)")
@@ -368,6 +370,38 @@ def side_config(args) -> int:
             loss.backward()
             opt.step()
             return loss
+    elif args.config in ("relaynet", "mgunet2"):
+        b = args.batch if args.batch != 32 else 16
+        h, w = (args.height, args.width) if (args.height, args.width) != (512, 1024) else (496, 768)
+        if args.config == "relaynet":
+            from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Lesions_Segment.ReLayNet_2017 import ReLayNet
+            ncls = 10
+            model = ReLayNet(1, ncls).to(dev).train()
+            name = "SOTAS/Lesions_Segment ReLayNet_2017.ReLayNet(1,10) (7x3 convolutions, 64 filters, pool-with-indices / unpool)"
+            # conv FLOPs of one forward: 3 encoders + bottleneck + 3 decoders, 7x3 taps, 64 filters; classifier 1x1
+            hw = [(h >> i, w >> i) for i in range(4)]
+            fwd = 2.0 * 21 * (hw[0][0] * hw[0][1] * 1 * 64 + hw[1][0] * hw[1][1] * 64 * 64 + hw[2][0] * hw[2][1] * 64 * 64
+                              + hw[3][0] * hw[3][1] * 64 * 64 + hw[2][0] * hw[2][1] * 128 * 64 + hw[1][0] * hw[1][1] * 128 * 64
+                              + hw[0][0] * hw[0][1] * 128 * 64) + 2.0 * h * w * 64 * ncls
+            flops = 3.0 * fwd - 2.0 * 21 * h * w * 64
+        else:
+            from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment.MGUNet_2021 import MGUNet_2
+            ncls = 11
+            model = MGUNet_2(1, ncls).to(dev).train()
+            name = "SOTAS/Layers_Segment MGUNet_2021.MGUNet_2(1,11) (feature_scale 4, multi-scale graph reasoning at the bottleneck)"
+            flops = 0.0
+        x = torch.randn(b, 1, h, w, generator=g).to(dev)
+        t = torch.randint(0, ncls, (b, h, w), generator=g).to(dev)
+        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+        unit, workload = "B-scans/s", f"{name} train step, {h}x{w}, batch {b}"
+        step_desc = "fwd + torch cross_entropy on the logits + bwd (autograd over the HIP ops layer) + torch SGD(momentum)"
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(model(x), t)
+            loss.backward()
+            opt.step()
+            return loss
     else:
         from retinal_oct_image_segmentation_via_deep_learning_amd.unet3d import UNet3D
         b = args.batch if args.batch != 32 else 4
@@ -403,10 +437,10 @@ def side_config(args) -> int:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": workload, "global_batch": b, "parallelism": "dp1", "step": step_desc + "; inputs resident in HBM"},
         "loss": float(loss),
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                     "kernel": "whole step (algorithmic conv FLOPs of the network / step time)",
-                     "flop_per_unit": flops},
+        "roofline": ({"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                      "kernel": "whole step (algorithmic conv FLOPs of the network / step time)",
+                      "flop_per_unit": flops} if flops else None),
         "cpu_baseline": None,
         "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
     return 0
@@ -494,7 +528,7 @@ def worker(args) -> int:
 
     if args.config != "cfg2":
         if args.gpus != 1 or args.dry_run:
-            print("bench.py: --config cfg1 / cfg4 / cfg5 are single-GPU lines", file=sys.stderr)
+            print("bench.py: --config cfg1 / cfg4 / cfg5 / relaynet / mgunet2 are single-GPU lines", file=sys.stderr)
             return 2
         return side_config(args)
     backend = "gloo" if args.dry_run and args.backend == "nccl" and not torch.cuda.is_available() else args.backend

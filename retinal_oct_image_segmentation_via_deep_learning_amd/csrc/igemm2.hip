@@ -91,10 +91,17 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
 // the 32x32x16 read pattern and 1 for the 16x16x32 one (each conflict-free for all three tap columns; exhaustive check in
 // tools/lds_swizzle_check.py).  Three (3x3) or six (1x1) LDS buffers: the DMAs of stage s + NBUF - 1 are issued while stage s
 // multiplies, the producers wait with a COUNTED vmcnt for stage s + 1 and the stage barrier is a raw s_barrier.
-template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS, bool RAGGED = false, bool D3 = false, bool DMA = false>
+// WLDS (Cout = 32 with Cin = 64: dec1 conv1 forward, the data gradient of enc2 conv1): the whole filter (36 KB) is copied into
+// LDS once per workgroup and the MFMA waves read their weight fragments from there.  Streamed from L2, every one of the four
+// waves fetched all 36 fragments per 16 x 32 tile -- 144 KB of weight requests next to 78 KB of activations on the
+// full-resolution layer, through the same per-CU load path: it ran at 3.9 TB/s where its 32 -> 32 siblings (resident
+// weights in registers) reach 5.4.  Registers cannot hold 36 fragments (144 VGPRs) beside the accumulators.
+template <int TAPS, int WM, int WN, int MF, int NF, bool WRES, bool STATS, bool RAGGED = false, bool D3 = false, bool DMA = false,
+          bool WLDS = false>
 __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   static_assert(WM * WN == 4, "four MFMA waves");
   static_assert(!DMA || (!WRES && !STATS && !RAGGED && !D3), "DMA staging: streamed weights, whole tiles, 2-D, no BatchNorm sums");
+  static_assert(!WLDS || (TAPS == 9 && !WRES && !D3 && !DMA && WN * NF == 1), "LDS-resident weights: 3x3, one 32-channel block");
   constexpr int TH = WM * MF, TW = 32;
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
@@ -148,13 +155,16 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // BN scale/shift of every input channel live in LDS: reading them with ds_read keeps them off the
   // vmcnt queue (a global load issued at commit time would be YOUNGER than the prefetched stages and
   // waiting for it would drain the whole ring -- vmcnt retires in order)
+  // WLDS trims the tables to what a 3x3 kernel with <= 64 input channels needs, to make room for the filter
+  constexpr int SXF_N = WLDS ? 64 : 1024, OSCR_SLOTS = WLDS ? 1 : 2, SBIAS_N = WLDS ? 0 : 1024, WLDS_BYTES = WLDS ? 2 * 18 * 1024 : 0;
   float* const sxf = reinterpret_cast<float*>(smem + NBUF * BUFB) + (2 * WM * 2 * NT + 4);
-  unsigned char* const oscr = smem + NBUF * BUFB + (2 * WM * 2 * NT + 4) * 4 + 2 * 1024 * 4;  // 2 slots x 4 waves x 32 px x 80 B
+  unsigned char* const oscr = smem + NBUF * BUFB + (2 * WM * 2 * NT + 4) * 4 + 2 * SXF_N * 4;  // OSCR_SLOTS x 4 waves x 32 px x 80 B
   static_assert((NBUF * BUFB + (2 * WM * 2 * NT + 4) * 4) % 16 == 0, "scratch must stay 16-B aligned");
-  float* const sbias = reinterpret_cast<float*>(oscr + 2 * 4 * 32 * 80);   // [cout/4] deconv bias (D2S only)
+  unsigned char* const wlds = oscr + OSCR_SLOTS * 4 * 32 * 80;               // [tap][k16][1 KB fragment] (WLDS)
+  float* const sbias = reinterpret_cast<float*>(wlds + WLDS_BYTES);          // [cout/4] deconv bias (D2S only)
   // streamed-weight kernels: BatchNorm partial sums of ALL items of this workgroup, [2][cout]; one row
   // per workgroup reaches memory instead of one per tile (bn_finalize then reads <= 512 rows, not 16 k)
-  float* const wgacc = sbias + 1024;
+  float* const wgacc = sbias + SBIAS_N;
   if (STATS && !WRES) {
     for (int i = tid; i < 2 * p.cout; i += 512) wgacc[i] = 0.f;
   }
@@ -168,6 +178,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     }
     if (d2s && p.bias)
       for (int i = tid; i < (p.cout >> 2); i += 512) sbias[i] = p.bias[i];
+    if constexpr (WLDS) {   // the filter of this 32-channel block, packed fragment order as it lies in memory
+      const u32x4* src = reinterpret_cast<const u32x4*>(p.wp);
+      u32x4* dst = reinterpret_cast<u32x4*>(wlds);
+      for (int i = tid; i < TAPS * p.nk16 * 64; i += 512) dst[i] = src[i];
+    }
   }
   __syncthreads();
 
@@ -233,6 +248,14 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         const bool ok = (code[i] & edge) == 0;
         const unsigned char* src = ok ? hb + goff[i] : zsrc;
         __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)(dst + i * 4096), 16, 0, 0);
+#ifndef IG2_DMA_SLEEP
+#define IG2_DMA_SLEEP 6
+#endif
+        // the producers have nothing else to do: pace the tile's requests over the stage instead of sending them as one burst
+        // in front of the MFMA waves' weight loads (same reasoning as SPREAD below); s_sleep counts 64-cycle units
+        // (the one-fragment kernels' stages are 2.3 k cycles: a third of the pause; same box, r3: -5...-7 % on the Cout >= 128
+        //  launches with 6, +3 % on the 64-channel ones with 6, neutral with 2)
+        if (TAPS == 9 && IG2_DMA_SLEEP > 0 && i + 1 < NSLOT) __builtin_amdgcn_s_sleep(NF == 2 ? IG2_DMA_SLEEP : IG2_DMA_SLEEP / 3);
       }
     };
     // all but the youngest NBUF - 2 stages have landed (vmcnt = simm16[15:14 | 3:0]); then the raw barrier
@@ -422,7 +445,8 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     // instead of as one burst behind it.  Why: the MFMA waves stream their weights from L2 through the same per-CU
     // load path, and while a burst of HBM-missing tile loads sat in it the weight loads' latency exceeded the ring's lead
     // (profiles/r03_ig2_traces.txt: stages that coincide with a new tile's loads ran 30-60 % longer).
-    const bool spread = IG2_PSPREAD && TAPS == 9 && !D3 && p.xf0 != 0 && (p.c1 == 0 || p.xf1 != 0);
+    // (not the resident-weight kernels: their MFMA waves load nothing, and an HBM-bound kernel wants its requests out early)
+    const bool spread = IG2_PSPREAD && TAPS == 9 && !D3 && !WRES && p.xf0 != 0 && (p.c1 == 0 || p.xf1 != 0);
     if (spread) {
       for (int s0 = 0; s0 < nstage_pad; s0 += D) {
 #pragma unroll
@@ -492,7 +516,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       for (int q = 0; q < NF; ++q) asm volatile("" : "+v"(wres[s][q]));
   }
 
-  constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? 3 : ((MF * NF >= 4) ? 6 : 9));
+#ifndef IG2_PF4
+#define IG2_PF4 9
+#endif
+  constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? 3 : ((MF * NF >= 4) ? IG2_PF4 : 9));   // PF4: 6 until round 3
   static_assert(KSTEPS % PF == 0, "ring slots must line up across stages");
   Frag wring[(WRES || M16) ? 1 : PF][NF];
   // M16: weights of two taps.  Tap t sits in slot t & 1 and tap t + 1 is fetched while it multiplies; a stage has nine taps,
@@ -506,7 +533,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // lead was ONE tap (~500 cycles), less than an L2 hit takes while the producers' loads of a new tile miss to HBM: the
   // stages that coincide with those loads ran 30-60 % longer (in-kernel timeline, profiles/r03_ig2_traces.txt: MFMA phase
   // 5.5 k cycles on even stages, 7.3-9.3 k on odd ones).
-  constexpr bool WR3 = IG2_WRING3 && M16;
+  constexpr bool WR3 = IG2_WRING3 && M16 && !RAGGED;   // (the ragged instantiations have no registers left for the third slot)
   constexpr int NWS = WR3 ? 3 : 2;
   Frag a16[M16 ? NWS : 1][M16 ? 2 * NF : 1];
   f32x16 acc[MF][NF];
@@ -752,13 +779,14 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       const size_t qstride = (size_t)TAPS * p.nk16 * 512, tstride = (size_t)p.nk16 * 512;
       if (!WRES) {
         const int nb0 = nbi * (NT / 32) + wn * NF;
-        wbase = p.wp + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512 + lane * 8;
+        const bf16_t* const wsrc = WLDS ? reinterpret_cast<const bf16_t*>(wlds) : p.wp;   // WLDS: nb0 = 0 (one 32-channel block)
+        wbase = wsrc + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512 + lane * 8;
         if constexpr (M16 && !STATS) wuni = p.wp + ((size_t)nb0 * TAPS * p.nk16 + ch * 2) * 512;
         int n_ch = ch + 1, n_item = item;
         if (n_ch == p.nch) { n_ch = 0; n_item = item + 1; }
         if (n_item >= nitems_wg) { n_item = item; n_ch = ch; }  // last stage: harmless re-read of valid memory
         const int n_nbi = n_item == item ? nbi : (nbi + 1 == p.nblk ? 0 : nbi + 1);
-        wbase_n = p.wp + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512 + lane * 8;
+        wbase_n = wsrc + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512 + lane * 8;
         if constexpr (M16 && !STATS) wuni_n = p.wp + ((size_t)(n_nbi * (NT / 32) + wn * NF) * TAPS * p.nk16 + n_ch * 2) * 512;
         if (sidx == 0 && !M16) {
 #pragma unroll
@@ -1206,6 +1234,27 @@ static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
     hipLaunchKernelGGL((igemm2_kernel<1, WM, WN, MF, NF, false, false>), dim3(grid), dim3(512), lds, s, p);
 }
 
+// LDS-resident weights (see WLDS in the kernel): Cout = 32, Cin <= 64, streamed-weight 3x3 kernels on whole tiles
+static bool wlds_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("OCT_IG2_WLDS"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+template <int WM, int MF>
+static void launch_v2_wlds(const Igemm2Params& p, int grid, hipStream_t s) {
+  constexpr int TH = WM * MF;
+  const int lds = 2 * (TH + 2) * 34 * 80 + (2 * WM * 2 * 32 + 4) * (int)sizeof(float) + 2 * 64 * (int)sizeof(float) + 4 * 32 * 80 + 2 * 18 * 1024 +
+                  (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, 1, MF, 1, false, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, 1, MF, 1, false, false, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, 1, MF, 1, false, true, false, false, false, true>), dim3(grid), dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((igemm2_kernel<9, WM, 1, MF, 1, false, false, false, false, false, true>), dim3(grid), dim3(512), lds, s, p);
+}
+
 // LDS-DMA staging (see the kernel): data gradients -- one source, no transform on load, whole 8-row tiles, streamed weights
 static bool dma_enabled() {
   static int on = -1;
@@ -1262,7 +1311,11 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
     else if (pl.nt == 64) launch_v2_1x1<2, 2, 4, 1>(p, pl.grid, s);
     else launch_v2_1x1<2, 2, 4, 2>(p, pl.grid, s);
   } else if (pl.nt == 32 && pl.th == 16) {
-    if (pl.wres) launch_v2<4, 1, 4, 1, true>(p, pl.grid, s); else launch_v2<4, 1, 4, 1, false>(p, pl.grid, s);
+    const bool wlds = wlds_enabled() && !pl.wres && d->cout == 32 && (d->c0 + d->c1) <= 64 && d->depth == 0 && d->out_img_mul == 0 &&
+                      (d->w % 32) == 0 && (d->h % 16) == 0;
+    if (pl.wres) launch_v2<4, 1, 4, 1, true>(p, pl.grid, s);
+    else if (wlds) launch_v2_wlds<4, 4>(p, pl.grid, s);
+    else launch_v2<4, 1, 4, 1, false>(p, pl.grid, s);
   } else if (pl.nt == 32) {
     if (pl.wres) launch_v2<4, 1, 2, 1, true>(p, pl.grid, s); else launch_v2<4, 1, 2, 1, false>(p, pl.grid, s);
   } else if (pl.nt == 64 && !pl.wres && pl.th == 16) {

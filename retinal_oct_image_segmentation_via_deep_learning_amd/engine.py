@@ -167,6 +167,7 @@ class UNetEngine:
         self._unpack_jobs = []
         self._nbt = []
         self._frozen_bwd = False
+        self.supports_frozen_bwd = True   # backward through an eval-mode forward (BatchNorm on running statistics)
         self._consts = {}  # (value, n, device) -> constant fp32 vector (never written)
         # OCT_ROWDOT=0: one-output-channel 1x1 convolutions stay on the padded MFMA kernels (A/B switch, parity tests)
         self.rowdot_off = os.environ.get("OCT_ROWDOT", "1") == "0"

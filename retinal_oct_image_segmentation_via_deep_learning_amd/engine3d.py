@@ -29,6 +29,7 @@ from .engine import (BN_EPS, BN_MOMENTUM, BNState, BlockSpec, ConvKeys, ConvRec,
 class UNet3DEngine(UNetEngine):
     def __init__(self, in_channels: int, out_channels: int, features: int = 32, dtype: str = "bf16"):
         super().__init__(in_channels, out_channels, features, dtype, spec=ynet_unet_spec(in_channels, out_channels, features))
+        self.supports_frozen_bwd = False   # (no reference counterpart; eval-mode forward is inference only)
 
     # ---- forward ------------------------------------------------------------------------------------
     def _conv_bn3(self, P, keys: ConvKeys, src: Src, cout, n, h, w, depth, train) -> ConvRec:

@@ -64,8 +64,9 @@ class _EngineNet(nn.Module):
     def _run(self, x, train: bool, keep_ctx=None, frozen_bwd=False):
         """The reference forward's return value: probabilities (YNet_2022 UNet) or logits (BioNet UNet)."""
         soft = self._engine.spec.softmax_out
+        kw = {"frozen_bwd": True} if frozen_bwd else {}
         ectx, probs, _, lg = self._engine.forward(self._tensors(), x, train=train, want_probs=soft,
-                                                  want_logits=not soft, frozen_bwd=frozen_bwd)
+                                                  want_logits=not soft, **kw)
         if keep_ctx is not None:
             keep_ctx.ectx = ectx
         return probs if soft else lg
@@ -95,7 +96,7 @@ class _EngineNet(nn.Module):
             # the reference nn.Module returns d(out)/d(x); the engine stops at the first layer's weights
             raise NotImplementedError("gradients with respect to the network INPUT are not implemented on the HIP "
                                       "path (x.requires_grad=True); detach the input")
-        if grad_on:
+        if grad_on and (self.training or self._engine.supports_frozen_bwd):
             return _UNetFn.apply(self, x, *self.parameters())
         return self._run(x, train=self.training)
 
