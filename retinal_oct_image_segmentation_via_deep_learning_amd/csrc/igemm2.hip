@@ -1280,6 +1280,10 @@ static void launch_v2_dma(const Igemm2Params& p, int grid, hipStream_t s) {
 int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
   const V2Plan pl = plan_v2(d);
   if (!pl.ok) return 0;
+  if (d->taps == 1) {   // transposed convolutions with N % 256 == 0: the eight-wave GEMM kernel (gemm1.hip)
+    const int rc = oct_conv_forward_g1(d, a, stream);
+    if (rc != 0) return rc;
+  }
   Igemm2Params p;
   p.x0 = (const bf16_t*)a->x0; p.x1 = (const bf16_t*)a->x1;
   p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;

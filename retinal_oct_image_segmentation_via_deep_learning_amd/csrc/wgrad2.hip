@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     for (int j = 0; j < SIB; ++j) {
       const int pix = pb + 64 * j;
       const int ly = pix / LW, lx = pix - ly * LW;
-      reli[j] = (ly - HALO) * p.w + (lx - HALO);
+      reli[j] = ly * p.w + lx;   // relative to the tile's halo corner: never negative (a scalar base + unsigned lane offset per load)
       // bottom / right flags against the LAST tile row / column of the image (see igemm2.hip): the halo
       // row / column for whole tiles, everything beyond H, W for a ragged size
       const int ylast = p.h - (p.tiles_y - 1) * TH + HALO, xlast = p.w - (p.tiles_x - 1) * TW + HALO;
@@ -205,13 +205,19 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         const int cg = ci_sb + blk * 32;
         const bool second = cg >= p.c0;
         const int cs = second ? p.c1 : p.c0;
-        const bf16_t* base = (second ? p.x1 + in_origin * p.c1 + (cg - p.c0) : p.x0 + in_origin * p.c0 + cg) + g * 8;
+        // wave-uniform 64-bit base = the tile's halo corner (it may lie outside the tensor: such slots are dead and read
+        // the tile origin instead) + an unsigned 32-bit lane offset: `global_load_dwordx4 v, v_off, s[base]` -- the per-lane
+        // 64-bit address arithmetic this replaces was 4-5 vector instructions per load, 20 loads per stage, on the waves
+        // the stage waits for (producers 5.76 k cycles against 5.35 k of MFMA phase, profiles/r02_wgrad2_timeline.txt)
+        const bf16_t* base = second ? p.x1 + in_origin * p.c1 + (cg - p.c0) : p.x0 + in_origin * p.c0 + cg;
+        const unsigned cs2 = 2u * (unsigned)cs, safe = (unsigned)(HALO * (p.w + 1)) * cs2 + (unsigned)g * 16u;
+        const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - (size_t)(HALO * (p.w + 1)) * cs2;
         // unconditional loads (see igemm2.hip): invalid slots re-read the tile origin, zeroed at commit
         unsigned vm = 0;
 #pragma unroll
         for (int j = 0; j < SIB; ++j) {
           const bool ok = (!D3 || zok) && (code[j] & edge) == 0;
-          S.ri[blk][j] = *reinterpret_cast<const u32x4*>(base + (ok ? __mul24(reli[j], cs) : 0));
+          S.ri[blk][j] = *reinterpret_cast<const u32x4*>(hb + (ok ? __umul24((unsigned)reli[j], cs2) + (unsigned)g * 16u : safe));
           vm |= ok ? (1u << j) : 0u;
         }
         S.vm[blk] = vm;
@@ -227,16 +233,18 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
           const int dydx = row / cs, co = row - dydx * cs;
           const int img2 = (D3 && p.dy_mul) ? img * p.dy_mul + p.dy_add : img;
           const size_t o2 = ((size_t)img2 * (2 * p.h) + 2 * tyi * TH + (dydx >> 1)) * (size_t)(2 * p.w) + 2 * txi * TW + (dydx & 1);
-          base = p.dy + o2 * cs + co + g * 8;
+          base = p.dy + o2 * cs + co;
         } else {
           cs = p.cout;
-          base = p.dy + origin * cs + row + g * 8;
+          base = p.dy + origin * cs + row;
         }
+        const unsigned cs2 = 2u * (unsigned)cs;
+        const unsigned char* const db = reinterpret_cast<const unsigned char*>(base);   // uniform base + unsigned lane offset
         unsigned vd = 0;
 #pragma unroll
         for (int j = 0; j < SDB; ++j) {
           const bool ok = !RAGGED || (dcode[j] & edge) == 0;   // dY pixels of a ragged last tile beyond the image
-          S.rd[blk][j] = *reinterpret_cast<const u32x4*>(base + (ok ? __mul24(reld[j], cs) : 0));
+          S.rd[blk][j] = *reinterpret_cast<const u32x4*>(db + ((ok ? __umul24((unsigned)reld[j], cs2) : 0u) + (unsigned)g * 16u));
           vd |= ok ? (1u << j) : 0u;
         }
         if (RAGGED) S.vd = vd;

@@ -184,7 +184,9 @@ def test_wgrad_bit_exact(env, shape):
     same(grad.cpu().numpy(), dw, "wgrad")
 
 
-DECONV = [(2, 16, 32, 64, 32), (1, 8, 64, 256, 128), (1, 8, 32, 512, 256), (1, 16, 64, 128, 64)]
+DECONV = [(2, 16, 32, 64, 32), (1, 8, 64, 256, 128), (1, 8, 32, 512, 256), (1, 16, 64, 128, 64),
+          # gemm1.hip (N % 256 == 0): several items per workgroup, an odd chunk count, both channel-block counts
+          (8, 32, 128, 64, 256), (4, 16, 64, 96, 64), (2, 16, 64, 256, 64), (3, 24, 32, 128, 192)]
 
 
 @pytest.mark.parametrize("shape", DECONV)
@@ -299,3 +301,51 @@ def test_conv3x3_wgrad_with_fused_bias_gradient_bit_exact(env, shape):
     _, dw = O.conv3x3_bwd(eff, np.zeros((cout, c0 + c1, 3, 3)), dy.astype(np.float64), need_dx=False)
     same(grad.cpu().numpy(), dw, "wgrad")
     same(db.cpu().numpy(), dy.astype(np.float64).sum(axis=(0, 2, 3)), "bias gradient")
+
+
+KK73 = [(2, 16, 32, 32, 0, 32), (1, 14, 40, 64, 0, 64), (1, 16, 32, 64, 64, 64), (2, 9, 24, 32, 0, 96)]
+
+
+@pytest.mark.parametrize("shape", KK73)
+def test_conv7x3_fprop_dgrad_wgrad_bit_exact(env, shape):
+    """ReLayNet's 7x3 convolution (ReLayNet_2017.py:155-160; padding (3, 1)) in bf16 on the (kh, kw) kernels: forward with the
+    on-load transform and the BatchNorm sums, data gradient with the concat split, weight gradient in its three row groups --
+    bit equality against torch's float64 convolution on the same exactly representable operands."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    L, E = env
+    n, h, w, c0, c1, cout = shape
+    cin = c0 + c1
+    rng = np.random.default_rng(abs(hash(shape)) % 2**32 + 73)
+    eng = ops.kernels("bf16")
+    src, eff = exact_src(E, rng, n, h, w, c0, c1, True)
+    wt = pow2_weights(rng, (cout, cin, 7, 3), density=0.35)
+    wd = fdev(wt)
+    kk = dict(kh=7, kw=3)
+    # forward
+    wp = ops.packed(eng, wd, L.PACK_CONV_FPROP, cout, cin, cache=False, kk=(7, 3))
+    y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    part = torch.full((eng._stat_blocks(cout, n, h, w, src, 21, **kk), 2, cout), float("nan"), dtype=torch.float32, device="cuda")
+    eng._conv(src, wp, cout, 21, n, h, w, y, stats=part, **kk)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(eff).double(), torch.from_numpy(wt).double(), padding=(3, 1)).numpy()
+    assert np.abs(ref).max() * 8 < 2 ** 22
+    same(host(y), to_bf16(ref), "7x3 fprop")
+    np.testing.assert_allclose(part.double().sum(0).cpu().numpy()[0], ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-2)
+    # data gradient (split over the two sources of a virtual concat)
+    dy = ints(rng, (n, cout, h, w), -2, 2) * (rng.random((n, cout, h, w)) < 0.5)
+    wpd = ops.packed(eng, wd, L.PACK_CONV_DGRAD, cout, cin, cache=False, kk=(7, 3))
+    d0 = torch.full((n, h, w, c0), float("nan"), dtype=torch.bfloat16, device="cuda")
+    d1 = torch.full((n, h, w, c1), float("nan"), dtype=torch.bfloat16, device="cuda") if c1 else None
+    eng._conv(E.Src(dev(dy), cout), wpd, cin, 21, n, h, w, d0, y1=d1, split=c0 if c1 else 0, **kk)
+    dx = torch.nn.grad.conv2d_input((n, cin, h, w), torch.from_numpy(wt).double(), torch.from_numpy(dy).double(), padding=(3, 1)).numpy()
+    same(host(d0), to_bf16(dx[:, :c0]), "7x3 dgrad part 0")
+    if c1:
+        same(host(d1), to_bf16(dx[:, c0:]), "7x3 dgrad part 1")
+    # weight gradient
+    dwp = eng._wgrad(src, dev(dy), cout, 21, n, h, w, partials_ok=False, **kk)
+    grad = torch.full((cout, cin, 7, 3), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(L.lib().oct_unpack_wgrad_kk(dwp.data_ptr(), grad.data_ptr(), cout, cin, 7, 3, 0, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    dw = torch.nn.grad.conv2d_weight(torch.from_numpy(eff).double(), (cout, cin, 7, 3), torch.from_numpy(dy.astype(np.float64)),
+                                     padding=(3, 1)).numpy()
+    assert np.abs(dw).max() * 2 < 2 ** 23
+    same(grad.cpu().numpy(), dw, "7x3 wgrad")

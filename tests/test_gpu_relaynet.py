@@ -110,12 +110,16 @@ def test_bf16_network_is_close_and_trains(golden_dir, name):
     loss = F.cross_entropy(out, t)
     np.testing.assert_allclose(float(loss.detach()), float(z["loss"][0]), rtol=2e-2)
     loss.backward()
-    cos = []
+    # per tensor: relative L2 distance to the reference's fp32 gradient (bf16 storage of every activation and of dY: ~2^-8
+    # per element, accumulating over the 3-7 layers between the loss and the tensor; round 2 only asked for a MEAN cosine > 0.9)
+    worst = {}
     for k, p in m.named_parameters():
         a, b = p.grad.flatten().double().cpu(), torch.from_numpy(z["g/" + k]).flatten().double()
         if float(b.norm()) > 1e-6 and b.numel() >= 8:
-            cos.append(float(a @ b / (a.norm() * b.norm() + 1e-30)))
-    assert np.mean(cos) > 0.9, (name, cos)
+            worst[k] = float((a - b).norm() / b.norm())
+    # (measured: 0.003-0.22 for the convolutions of the full-resolution levels, 0.32-0.42 for the bottleneck of the tiny fixture,
+    #  whose BatchNorm sees 48 samples per channel: tests/probes/bf16_probe.py -- two valid bf16 evaluations differ as much there)
+    assert max(worst.values()) < 0.5 and np.median(list(worst.values())) < 0.1, (name, worst)
     opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
     losses = []
     for _ in range(5):

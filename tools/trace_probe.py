@@ -13,8 +13,9 @@ eng = E.UNetEngine(1, 2, 4, "bf16")
 bf = torch.bfloat16
 x0 = torch.randn(n, h, w, c0, device="cuda").to(bf)
 x1 = torch.randn(n, h, w, c1, device="cuda").to(bf) if c1 else None
-bn0 = E.BNState(torch.rand(c0, device="cuda") + 0.5, torch.randn(c0, device="cuda") * 0.1)
-bn1 = E.BNState(torch.rand(c1, device="cuda") + 0.5, torch.randn(c1, device="cuda") * 0.1) if c1 else None
+noxf = bool(os.environ.get("TRACE_NOXF"))   # no transform on load: the data-gradient case (LDS-DMA staging when eligible)
+bn0 = None if noxf else E.BNState(torch.rand(c0, device="cuda") + 0.5, torch.randn(c0, device="cuda") * 0.1)
+bn1 = E.BNState(torch.rand(c1, device="cuda") + 0.5, torch.randn(c1, device="cuda") * 0.1) if (c1 and not noxf) else None
 src = E.Src(x0, c0, bn0, x1, c1, bn1)
 wt = torch.randn(cout, c0 + c1, 3, 3, device="cuda") * 0.05
 wp = eng._pack("w", wt, L.PACK_CONV_FPROP, cout, c0 + c1)
