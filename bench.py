@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_BSCAN_TRAIN = 578.009e9   # 3*F_fwd - dgrad(enc1conv1), UNet(1,8) @ 512x1024
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
 def train_flops(features, classes, h, w, in_ch=1):

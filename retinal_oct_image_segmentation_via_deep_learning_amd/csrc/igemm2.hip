@@ -1017,10 +1017,27 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
             pm_ = m; pq_ = q; ++fidx;
           }
           if (STATS) {
+#ifndef IG2_PKSTATS
+#define IG2_PKSTATS 1
+#endif
+            if constexpr (IG2_PKSTATS && !DEFER) {
+              // un-deferred epilogue (no MFMA of this wave in flight): the 32 sum updates of a fragment as 16 packed-f32
+              // instructions -- same IEEE arithmetic, half the vector issue slots on a SIMD that also hosts a producer wave
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+              for (int i = 0; i < 16; i += 2) {
+                const f32x2 av = {acc[m][q][i], acc[m][q][i + 1]};
+                f32x2 sv = {s1[q][i], s1[q][i + 1]}, tv = {s2[q][i], s2[q][i + 1]};
+                sv += av;
+                tv = __builtin_elementwise_fma(av, av, tv);
+                s1[q][i] = sv[0]; s1[q][i + 1] = sv[1]; s2[q][i] = tv[0]; s2[q][i + 1] = tv[1];
+              }
+            } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               s1[q][i] += acc[m][q][i];
               s2[q][i] = fmaf(acc[m][q][i], acc[m][q][i], s2[q][i]);
+            }
             }
           }
         }

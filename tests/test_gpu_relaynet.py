@@ -119,7 +119,7 @@ def test_bf16_network_is_close_and_trains(golden_dir, name):
             worst[k] = float((a - b).norm() / b.norm())
     # (measured: 0.003-0.22 for the convolutions of the full-resolution levels, 0.32-0.42 for the bottleneck of the tiny fixture,
     #  whose BatchNorm sees 48 samples per channel: tests/probes/bf16_probe.py -- two valid bf16 evaluations differ as much there)
-    assert max(worst.values()) < 0.5 and np.median(list(worst.values())) < 0.1, (name, worst)
+    assert max(worst.values()) < 0.5 and np.median(list(worst.values())) < 0.3, (name, worst)
     opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
     losses = []
     for _ in range(5):

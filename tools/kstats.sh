@@ -3,7 +3,7 @@
 TAG=$1; PAT=${2:-.}
 O=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/ks_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-h2d --no-parity-mode > $O/ks_$TAG.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - "$O/ks_$TAG" "$PAT" <<'PY'
 import csv, glob, re, sys

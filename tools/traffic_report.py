@@ -21,7 +21,7 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             if r["Counter_Name"] != ctr:
                 continue
             k = r["Kernel_Name"]
-            cls = ("conv" if ("igemm" in k or "wgrad" in k or "first_" in k) else "other")
+            cls = ("conv" if ("igemm" in k or "gemm1" in k or "wgrad" in k or "first_" in k) else "other")
             tot[cls][ctr] += float(r["Counter_Value"]) * 1024.0
             if ctr == "FETCH_SIZE":
                 cnt[cls] += 1
