@@ -247,7 +247,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       for (int i = 0; i < NSLOT; ++i) {
         const bool ok = (code[i] & edge) == 0;
         const unsigned char* src = ok ? hb + goff[i] : zsrc;
-        __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)(dst + i * 4096), 16, 0, 0);
+#ifndef IG2_DMA_NT
+#define IG2_DMA_NT 0
+#endif
+        __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)(dst + i * 4096), 16, 0, IG2_DMA_NT ? 2 : 0);
 #ifndef IG2_DMA_SLEEP
 #define IG2_DMA_SLEEP 6
 #endif
@@ -366,7 +369,11 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     };
     auto issue_slot = [&](const IssueSt& st, int i, u32x4& r, unsigned& vm) {
       const bool ok = (!D3 || st.zok) && (code[i] & st.edge) == 0;
-      r = *reinterpret_cast<const u32x4*>(st.hb + (ok ? __umul24((unsigned)relp[i], st.cs2) : st.safe));
+#ifndef IG2_PNT
+#define IG2_PNT 0
+#endif
+      if (IG2_PNT) r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(st.hb + (ok ? __umul24((unsigned)relp[i], st.cs2) : st.safe)));
+      else r = *reinterpret_cast<const u32x4*>(st.hb + (ok ? __umul24((unsigned)relp[i], st.cs2) : st.safe));
       vm |= ok ? (1u << i) : 0u;
     };
     auto issue = [&](u32x4 (&Rr)[NSLOT], unsigned& vm) {
@@ -492,7 +499,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // ================================= MFMA waves (4) =================================
   // each SIMD hosts one MFMA wave and one producer wave: the MFMA wave must win issue arbitration
   // against the partner's VALU-dense staging code (static priority, MI355X_MICROARCH.md item 4)
-  __builtin_amdgcn_s_setprio(3);
+#ifndef IG2_MFMA_PRIO
+#define IG2_MFMA_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(IG2_MFMA_PRIO);
   const int r = lane & 31, hh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -533,7 +543,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   // lead was ONE tap (~500 cycles), less than an L2 hit takes while the producers' loads of a new tile miss to HBM: the
   // stages that coincide with those loads ran 30-60 % longer (in-kernel timeline, profiles/r03_ig2_traces.txt: MFMA phase
   // 5.5 k cycles on even stages, 7.3-9.3 k on odd ones).
-  constexpr bool WR3 = IG2_WRING3 && M16 && !RAGGED;   // (the ragged instantiations have no registers left for the third slot)
+#ifndef IG2_WR3_RAGGED
+#define IG2_WR3_RAGGED 0
+#endif
+  constexpr bool WR3 = IG2_WRING3 && M16 && (!RAGGED || IG2_WR3_RAGGED);   // (the ragged instantiations spill 6-10 dwords with the third slot)
   constexpr int NWS = WR3 ? 3 : 2;
   Frag a16[M16 ? NWS : 1][M16 ? 2 * NF : 1];
   f32x16 acc[MF][NF];

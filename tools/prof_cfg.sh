@@ -4,7 +4,7 @@
 TAG=$1; CFG=$2; STEPS=${3:-3}
 O=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-h2d > $O/ks_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-h2d --no-parity-mode > $O/ks_$TAG.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - "$O/ks_$TAG" "$STEPS" "$CFG" <<'PY'
 import csv, glob, sys
