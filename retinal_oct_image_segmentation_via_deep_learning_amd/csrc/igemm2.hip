@@ -71,7 +71,7 @@ __device__ __forceinline__ float bf16hi(unsigned u) { return __uint_as_float(u &
 #define IG2_PIXB16 96
 #endif
 // which instantiations multiply with v_mfma_f32_16x16x32_bf16 (see M16 in the kernel)
-template <int TAPS, int NF, bool WRES> constexpr bool ig2_m16() { return IG2_M16 && TAPS == 9 && !WRES && (NF == 2 || IG2_M16_NF1); }
+template <int TAPS, int NF, bool WRES> constexpr bool ig2_m16() { return IG2_M16 && TAPS != 1 && !WRES && (NF == 2 || IG2_M16_NF1); }
 // Pixel pitch of the LDS halo tile (bytes; 32 bf16 = 64 B of payload).  Register staging pads the pixel so that a wave's
 // ds_read_b128 of one fragment touches every bank once -- and which pad does that depends on the lane -> pixel map of the
 // MFMA shape (bank model of MI355X_MICROARCH.md, LDS: ds_read_b128 is serviced in four 16-lane groups):
@@ -103,13 +103,15 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
   static_assert(!DMA || (!WRES && !STATS && !RAGGED && !D3), "DMA staging: streamed weights, whole tiles, 2-D, no BatchNorm sums");
   static_assert(!WLDS || (TAPS == 9 && !WRES && !D3 && !DMA && WN * NF == 1), "LDS-resident weights: 3x3, one 32-channel block");
   constexpr int TH = WM * MF, TW = 32;
-  constexpr int HALO = (TAPS == 9) ? 1 : 0;
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  // TAPS = 9: 3x3; TAPS = 21: 7x3 (ReLayNet_2017.py:155-160, padding (3, 1)): tap = ky * 3 + kx either way; TAPS = 1: 1x1
+  constexpr int HALO = (TAPS != 1) ? 1 : 0;              // columns
+  constexpr int HALO_Y = (TAPS == 21) ? 3 : HALO;        // rows
+  constexpr int LH = TH + 2 * HALO_Y, LW = TW + 2 * HALO;
   constexpr int NPIX = LH * LW;
   constexpr int NSLOT = (NPIX + 63) / 64;       // producers (4 waves): 64 pixels x 4 channel groups per pass
   constexpr int PIXB = ig2_pixb<TAPS, NF, WRES, DMA>();
   constexpr int BUFB = DMA ? NSLOT * 4096 : NPIX * PIXB;
-  constexpr int NBUF = DMA ? (TAPS == 9 ? 3 : 6) : 2;
+  constexpr int NBUF = DMA ? (TAPS != 1 ? 3 : 6) : 2;
   constexpr int NT = WN * NF * 32;
   constexpr int KSTEPS = TAPS * 2;              // k16 steps per 32-channel chunk
   // M16: the streamed-weight 3x3 kernels multiply with v_mfma_f32_16x16x32_bf16 -- 18 half-steps (tap, 16-pixel half) of
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       const int relp = s2d ? (2 * ly) * (2 * p.w) + 2 * lx : ly * p.w + lx;   // relative to the halo corner
       goff[i] = (unsigned)relp * cs2 + (unsigned)((grp ^ ((lx >> KSH) & 3)) * 16);
       unsigned c = pix >= NPIX ? 16u : 0u;
-      if (HALO) c |= (ly == 0 ? 1u : 0u) | (lx == 0 ? 4u : 0u) | (ly == LH - 1 ? 2u : 0u) | (lx == LW - 1 ? 8u : 0u);
+      if (HALO) c |= (ly < HALO_Y ? 1u : 0u) | (lx == 0 ? 4u : 0u) | (ly >= LH - HALO_Y ? 2u : 0u) | (lx == LW - 1 ? 8u : 0u);
       code[i] = c;
     }
     const int last = nstage - 1;
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         base = p.x0 + (((size_t)img * p.h + tyi * TH) * p.w + txi * TW) * p.c0 + ch * 32;
       }
       // the tile's halo corner (it may lie outside the tensor: such lanes read the zero block instead)
-      const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - (size_t)(HALO * (p.w + 1)) * cs2;
+      const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - (size_t)(HALO_Y * p.w + HALO) * cs2;
       unsigned char* const dst = buf + pw * 1024;
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         // in front of the MFMA waves' weight loads (same reasoning as SPREAD below); s_sleep counts 64-cycle units
         // (the one-fragment kernels' stages are 2.3 k cycles: a third of the pause; same box, r3: -5...-7 % on the Cout >= 128
         //  launches with 6, +3 % on the 64-channel ones with 6, neutral with 2)
-        if (TAPS == 9 && IG2_DMA_SLEEP > 0 && i + 1 < NSLOT) __builtin_amdgcn_s_sleep(NF == 2 ? IG2_DMA_SLEEP : IG2_DMA_SLEEP / 3);
+        if (TAPS != 1 && IG2_DMA_SLEEP > 0 && i + 1 < NSLOT) __builtin_amdgcn_s_sleep(NF == 2 ? IG2_DMA_SLEEP : IG2_DMA_SLEEP / 3);
       }
     };
     // all but the youngest NBUF - 2 stages have landed (vmcnt = simm16[15:14 | 3:0]); then the raw barrier
@@ -299,9 +301,9 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // bottom / right flags are set against the LAST tile row / column of the image: for whole tiles that is
       // the halo row / column (zero padding), for a ragged size also every local row / column beyond H, W.
       // They only take effect on tiles of that last row / column (edge bits 1 and 3 below).
-      const int ylast = p.h - (p.tiles_y - 1) * TH + HALO, xlast = p.w - (p.tiles_x - 1) * TW + HALO;
+      const int ylast = p.h - (p.tiles_y - 1) * TH + HALO_Y, xlast = p.w - (p.tiles_x - 1) * TW + HALO;
       unsigned c = pix >= NPIX ? 16u : 0u;
-      if (HALO) c |= (ly == 0 ? 1u : 0u) | (lx == 0 ? 4u : 0u);
+      if (HALO) c |= (ly < HALO_Y ? 1u : 0u) | (lx == 0 ? 4u : 0u);
       c |= (ly >= ylast ? 2u : 0u) | (lx >= xlast ? 8u : 0u);
       code[i] = c;
     }
@@ -363,7 +365,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // use, which drains the whole multi-stage prefetch ring.
       // scalar 64-bit base (the tile's halo corner; it may lie outside the tensor, dead slots read the tile
       // origin instead) + unsigned 32-bit lane offset: one global_load with an SGPR base per slot
-      const unsigned cs2 = 2u * (unsigned)cs, safe = (unsigned)(HALO * (p.w + 1)) * cs2;
+      const unsigned cs2 = 2u * (unsigned)cs, safe = (unsigned)(HALO_Y * p.w + HALO) * cs2;
       const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - safe;
       return IssueSt{hb, edge, cs2, safe, zok};
     };
@@ -453,7 +455,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     // load path, and while a burst of HBM-missing tile loads sat in it the weight loads' latency exceeded the ring's lead
     // (profiles/r03_ig2_traces.txt: stages that coincide with a new tile's loads ran 30-60 % longer).
     // (not the resident-weight kernels: their MFMA waves load nothing, and an HBM-bound kernel wants its requests out early)
-    const bool spread = IG2_PSPREAD && TAPS == 9 && !D3 && !WRES && p.xf0 != 0 && (p.c1 == 0 || p.xf1 != 0);
+    const bool spread = IG2_PSPREAD && TAPS != 1 && !D3 && !WRES && p.xf0 != 0 && (p.c1 == 0 || p.xf1 != 0);
     if (spread) {
       for (int s0 = 0; s0 < nstage_pad; s0 += D) {
 #pragma unroll
@@ -529,7 +531,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #ifndef IG2_PF4
 #define IG2_PF4 9
 #endif
-  constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? 3 : ((MF * NF >= 4) ? IG2_PF4 : 9));   // PF4: 6 until round 3
+  constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? 3 : ((MF * NF >= 4) ? (TAPS == 21 ? 7 : IG2_PF4) : 9));   // PF4: 6 until round 3 (42 steps: 7)
   static_assert(KSTEPS % PF == 0, "ring slots must line up across stages");
   Frag wring[(WRES || M16) ? 1 : PF][NF];
   // M16: weights of two taps.  Tap t sits in slot t & 1 and tap t + 1 is fetched while it multiplies; a stage has nine taps,
@@ -547,7 +549,14 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #define IG2_WR3_RAGGED 0
 #endif
   constexpr bool WR3 = IG2_WRING3 && M16 && (!RAGGED || IG2_WR3_RAGGED);   // (the ragged instantiations spill 6-10 dwords with the third slot)
-  constexpr int NWS = WR3 ? 3 : 2;
+#ifndef IG2_WRING4
+#define IG2_WRING4 0
+#endif
+  // WR4: FOUR weight slots (tap t + 3 fetched while tap t multiplies: three taps = ~1.5 k matrix cycles of lead).  Nine taps do not
+  // line up with four slots: the next stage's taps 0-2 land in slots 1-3 and are moved down by one when that stage starts
+  // (48 v_mov per stage).  The 16 registers come from the activation fragments: a ring of six instead of two sets of four.
+  constexpr bool WR4 = IG2_WRING4 && WR3 && MF == 4;
+  constexpr int NWS = WR4 ? 4 : (WR3 ? 3 : 2);
   Frag a16[M16 ? NWS : 1][M16 ? 2 * NF : 1];
   f32x16 acc[MF][NF];
   float s1[STATS ? NF : 1][16], s2[STATS ? NF : 1][16];  // BN partial sums (lane = pixel column)
@@ -813,12 +822,12 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       const unsigned char* lb = tb + ((wm * MF) * LW + r) * PIXB + 8 * hh * 2;
       auto xoff = [](int s, int m) constexpr {
         const int tap = s >> 1, k16 = s & 1;
-        const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
+        const int ty = (TAPS != 1) ? tap / 3 : 0, tx = (TAPS != 1) ? tap % 3 : 0;
         return ((m + ty) * LW + tx) * PIXB + k16 * 32;
       };
       // DMA tiles (dense, swizzled): the chunk position depends on the tile column r + tx, so each (tx, k16) has its own
       // lane base; the row (m + ty) stays a compile-time offset
-      constexpr int NTX = (TAPS == 9) ? 3 : 1;
+      constexpr int NTX = (TAPS != 1) ? 3 : 1;
       unsigned lbs[DMA ? NTX : 1][2];   // byte offsets from smem (32-bit: six 64-bit pointers cost the dgrad kernels their last registers)
       if constexpr (DMA && !M16) {
 #pragma unroll
@@ -832,7 +841,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       auto xptr = [&](int s, int m) -> const unsigned char* {
         if constexpr (DMA) {
           const int tap = s >> 1, k16 = s & 1;
-          const int ty = (TAPS == 9) ? tap / 3 : 0, tx = (TAPS == 9) ? tap % 3 : 0;
+          const int ty = (TAPS != 1) ? tap / 3 : 0, tx = (TAPS != 1) ? tap % 3 : 0;
           return smem + (lbs[tx][k16] + (unsigned)((m + ty) * LW * 64));
         } else return lb + xoff(s, m);
       };
@@ -880,10 +889,52 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #pragma unroll
             for (int c = 0; c < 2 * NF; ++c) a16[1][c] = wfrag(false, c, 1);
           }
+          if constexpr (WR4) {
+#pragma unroll
+            for (int c = 0; c < 2 * NF; ++c) a16[2][c] = wfrag(false, c, 2);
+          }
+        } else if constexpr (WR4) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2 * NF; ++c) a16[j][c] = a16[j + 1][c];   // taps 0-2 of this stage, fetched under the previous one's taps 6-8
         } else if constexpr (!WR3) {
 #pragma unroll
           for (int c = 0; c < 2 * NF; ++c) a16[0][c] = a16[1][c];   // fetched under the previous stage's last tap
         }
+        if constexpr (WR4) {
+          // activation fragments f = s * MF + m (72 per stage) through a ring of six: the read of fragment f + 5 is issued before
+          // the MFMAs of fragment f (320 matrix cycles of lead)
+          constexpr int RB = 6, NFRAG = KSTEPS * MF;
+          static_assert(NFRAG % RB == 0, "the fragment ring must line up across stages");
+          Frag bq[RB];
+#pragma unroll
+          for (int f = 0; f < RB - 1; ++f) bq[f] = M::load(bptr(f / MF, f % MF));
+#pragma unroll
+          for (int s = 0; s < KSTEPS; ++s) {
+            const int t = s >> 1;
+#ifndef ABL_NO_WLOAD
+            if ((s & 1) == 0) {   // weights of tap t + 3 (the next stage's taps 0-2 under this one's taps 6-8)
+              const int t2 = t + 3;
+              const int tt = t2 < TAPS ? t2 : t2 - TAPS;
+#pragma unroll
+              for (int c = 0; c < 2 * NF; ++c) a16[t2 % 4][c] = wfrag(t2 >= TAPS, c, tt);
+            }
+#endif
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+              const int f = s * MF + m;
+              if (f + RB - 1 < NFRAG) bq[(f + RB - 1) % RB] = M::load(bptr((f + RB - 1) / MF, (f + RB - 1) % MF));
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int c = 0; c < 2 * NF; ++c) {
+                const Frag& wf = a16[t % 4][c];
+                if (s & 1) { if (c & 1) M::template mma16<3>(acc[m][c >> 1], wf, bq[f % RB]); else M::template mma16<2>(acc[m][c >> 1], wf, bq[f % RB]); }
+                else { if (c & 1) M::template mma16<1>(acc[m][c >> 1], wf, bq[f % RB]); else M::template mma16<0>(acc[m][c >> 1], wf, bq[f % RB]); }
+              }
+            }
+          }
+        } else {
         Frag b16[2][MF];
 #pragma unroll
         for (int m = 0; m < MF; ++m) b16[0][m] = M::load(bptr(0, m));
@@ -920,6 +971,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           for (int idx = EHANDLED; idx < NFR; ++idx) store_frag(idx / NF, idx % NF);
           pend = false;
         }
+        }   // !WR4
       } else {
       // ring of LD+1 fragment sets: the reads of step s+LD are in flight while step s multiplies
 #ifndef IG2_LD8
@@ -1169,7 +1221,13 @@ static bool v2_enabled() {
 static V2Plan plan_v2(const OctConvDesc* d) {
   V2Plan pl = {};
   if (!v2_enabled()) return pl;
-  if (d->kh == 7) return pl;   // 7x3: generic kernels
+  if (d->kh == 7) {
+    // 7x3 (ReLayNet): the 64- and 128-channel tilings with three halo rows above and below an 8-row tile.  A last tile row of
+    // one or two image rows would put padding into the bottom halo of the tile row ABOVE it, which the border codes do not
+    // express (they flag rows against the last tile row only): such heights stay on the generic kernel.
+    const int rem = d->h % 8;
+    if (d->taps != 21 || d->kw != 3 || d->depth > 0 || d->out_img_mul != 0 || rem == 1 || rem == 2 || (d->cout % 64) != 0) return pl;
+  }
   if ((d->depth > 0 || d->out_img_mul != 0) && ((d->w % 32) != 0 || (d->h % 16) != 0)) return pl;   // volumetric: whole tiles
   const int cin = d->in_mode == OCT_IN_S2D ? (d->depth > 0 ? 8 : 4) * d->c0 : d->c0 + d->c1;   // channels per depth tap
   // plain 3x3: any H, W (ragged last tiles are predicated); the deconv modes need whole tiles
@@ -1180,7 +1238,7 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   pl.ok = d->dtype == OCT_DT_BF16 && (whole || plain) && (d->c0 % 32) == 0 &&
           (d->c1 % 32) == 0 && (d->cout % 32) == 0 && (d->split % 32) == 0;
   pl.ok = pl.ok && (d->c0 + d->c1) <= 1024 && d->cout <= 4096;   // LDS tables: 2 x 1024 BN coefficients, 1024 bias values
-  if (d->taps == 9) pl.ok = pl.ok && plain;
+  if (d->taps != 1) pl.ok = pl.ok && plain;
   else pl.ok = pl.ok && (plain ||
                (!d->want_stats && d->split == 0 &&
                 ((d->in_mode == OCT_IN_PLAIN && d->out_mode == OCT_OUT_D2S && ((d->cout >> 2) % 32) == 0) ||
@@ -1214,38 +1272,39 @@ int oct_conv_v2_stat_rows(const OctConvDesc* d) {
   return pl.ok ? pl.stat_rows : -1;
 }
 
-template <int WM, int WN, int MF, int NF, bool WRES>
+template <int WM, int WN, int MF, int NF, bool WRES, int TAPS = 9>
 static void launch_v2(const Igemm2Params& p, int grid, hipStream_t s) {
   constexpr int TH = WM * MF;
-  const int lds = 2 * (TH + 2) * 34 * ig2_pixb<9, NF, WRES, false>() + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 2 * 4 * 32 * 80 + 1024 * (int)sizeof(float) +
+  constexpr int LH = TH + (TAPS == 21 ? 6 : 2);   // halo rows: 3 + 3 for the 7x3 kernel
+  const int lds = 2 * LH * 34 * ig2_pixb<TAPS, NF, WRES, false>() + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 2 * 4 * 32 * 80 + 1024 * (int)sizeof(float) +
                   (p.stats ? 2 * p.cout * (int)sizeof(float) : 0);
   {
     // > 64 KB of dynamic LDS: opt in once per instantiation (all eight variants of this shape share the size class)
     static bool attr = false;
     if (!attr) {
       const int cap = 160 * 1024;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, WRES, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, WRES, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      if constexpr (!WRES) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<9, WM, WN, MF, NF, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<TAPS, WM, WN, MF, NF, WRES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<TAPS, WM, WN, MF, NF, WRES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<TAPS, WM, WN, MF, NF, WRES, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<TAPS, WM, WN, MF, NF, WRES, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      if constexpr (!WRES && TAPS == 9) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<TAPS, WM, WN, MF, NF, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<TAPS, WM, WN, MF, NF, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
       }
       attr = true;
     }
   }
   const bool ragged = (p.w % 32) != 0 || (p.h % TH) != 0;
   if (p.depth > 0) {   // volumetric: whole tiles only (plan_v2), streamed weights
-    if constexpr (!WRES) {
-      if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, false, true, false, true>), dim3(grid), dim3(512), lds, s, p);
-      else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, false, false, false, true>), dim3(grid), dim3(512), lds, s, p);
+    if constexpr (!WRES && TAPS == 9) {
+      if (p.stats) hipLaunchKernelGGL((igemm2_kernel<TAPS, WM, WN, MF, NF, false, true, false, true>), dim3(grid), dim3(512), lds, s, p);
+      else hipLaunchKernelGGL((igemm2_kernel<TAPS, WM, WN, MF, NF, false, false, false, true>), dim3(grid), dim3(512), lds, s, p);
     }
   } else if (ragged) {
-    if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true, true>), dim3(grid), dim3(512), lds, s, p);
-    else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false, true>), dim3(grid), dim3(512), lds, s, p);
-  } else if (p.stats) hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(512), lds, s, p);
-  else hipLaunchKernelGGL((igemm2_kernel<9, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(512), lds, s, p);
+    if (p.stats) hipLaunchKernelGGL((igemm2_kernel<TAPS, WM, WN, MF, NF, WRES, true, true>), dim3(grid), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((igemm2_kernel<TAPS, WM, WN, MF, NF, WRES, false, true>), dim3(grid), dim3(512), lds, s, p);
+  } else if (p.stats) hipLaunchKernelGGL((igemm2_kernel<TAPS, WM, WN, MF, NF, WRES, true>), dim3(grid), dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((igemm2_kernel<TAPS, WM, WN, MF, NF, WRES, false>), dim3(grid), dim3(512), lds, s, p);
 }
 template <int WM, int WN, int MF, int NF>
 static void launch_v2_1x1(const Igemm2Params& p, int grid, hipStream_t s) {
@@ -1293,8 +1352,8 @@ static bool dma_enabled() {
 }
 template <int TAPS, int WM, int WN, int MF, int NF>
 static void launch_v2_dma(const Igemm2Params& p, int grid, hipStream_t s) {
-  constexpr int TH = WM * MF, HALO = TAPS == 9 ? 1 : 0;
-  constexpr int NSLOT = ((TH + 2 * HALO) * (32 + 2 * HALO) + 63) / 64, NBUF = TAPS == 9 ? 3 : 6;
+  constexpr int TH = WM * MF, HALO = TAPS != 1 ? 1 : 0, HALO_Y = TAPS == 21 ? 3 : HALO;
+  constexpr int NSLOT = ((TH + 2 * HALO_Y) * (32 + 2 * HALO) + 63) / 64, NBUF = TAPS != 1 ? 3 : 6;
   constexpr int lds = NBUF * NSLOT * 4096 + (2 * WM * 2 * (WN * NF * 32) + 4 + 2 * 1024) * (int)sizeof(float) + 2 * 4 * 32 * 80 + 1024 * (int)sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr = false;
@@ -1336,10 +1395,13 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
   hipStream_t s = as_stream(stream);
   const bool dma = dma_enabled() && !d->xform0 && !d->xform1 && d->c1 == 0 && !d->want_stats && !pl.wres && pl.th == 8 &&
                    d->depth == 0 && d->out_img_mul == 0 && (d->w % 32) == 0 && (d->h % 8) == 0 && pl.nt >= 64 &&
-                   ((d->taps == 9) || (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN));
+                   ((d->taps != 1) || (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN));
   if (dma) {
     if (d->taps == 9) { if (pl.nt == 64) launch_v2_dma<9, 2, 2, 4, 1>(p, pl.grid, s); else launch_v2_dma<9, 2, 2, 4, 2>(p, pl.grid, s); }
+    else if (d->taps == 21) { if (pl.nt == 64) launch_v2_dma<21, 2, 2, 4, 1>(p, pl.grid, s); else launch_v2_dma<21, 2, 2, 4, 2>(p, pl.grid, s); }
     else { if (pl.nt == 64) launch_v2_dma<1, 2, 2, 4, 1>(p, pl.grid, s); else launch_v2_dma<1, 2, 2, 4, 2>(p, pl.grid, s); }
+  } else if (d->taps == 21) {
+    if (pl.nt == 64) launch_v2<2, 2, 4, 1, false, 21>(p, pl.grid, s); else launch_v2<2, 2, 4, 2, false, 21>(p, pl.grid, s);
   } else if (d->taps == 1) {
     if (pl.nt == 32) launch_v2_1x1<4, 1, 2, 1>(p, pl.grid, s);
     else if (pl.nt == 64) launch_v2_1x1<2, 2, 4, 1>(p, pl.grid, s);

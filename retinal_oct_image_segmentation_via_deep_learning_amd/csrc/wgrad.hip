@@ -230,6 +230,9 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
     if (took == 0 && a->dy_coef) OCT_CHECK(false, "oct_conv_wgrad: the fused BN-backward apply is only implemented for the 1->F first layer in bf16");
     if (took == 0) took = oct_conv_wgrad_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
+  } else {
+    const int took = oct_conv_wgrad_v2(d, a, stream);   // 64-channel-block shapes: three row-shifted launches of the 3x3 kernel
+    if (took != 0) return took < 0 ? took : OCT_OK;
   }
   WgradParams p;
   p.x0 = a->x0; p.x1 = a->x1; p.sc0 = a->scale0; p.sh0 = a->shift0; p.sc1 = a->scale1; p.sh1 = a->shift1;
@@ -286,7 +289,7 @@ extern "C" int oct_conv_wgrad_partials(const OctWgradDesc* d) {
   if (kh != 7) {
     if (oct_first_wgrad(d, nullptr, nullptr, &q) == 1) return q;
     if (oct_conv_wgrad_v2(d, nullptr, nullptr, &q) == 1) return q;
-  }
+  } else if (oct_conv_wgrad_v2(d, nullptr, nullptr, &q) == 1) return q;
   const int ktot = d->c0 + d->c1;
   const int nco = ceil_div(d->cout, 32), nci = ceil_div(ktot, 32);
   const int ntiles = ceil_div(d->w, 32) * ceil_div(d->h, 8) * d->n;

@@ -29,6 +29,9 @@ struct Wgrad2Params {
   // into its own slab dwp[slab][tap][cout][ktot] (and dbias_part[slab][cout]); oct_unpack_wgrad sums the slabs in order.
   // No atomics: the result does not depend on scheduling, and nothing has to be zeroed.
   int part_mode; size_t slab_elems; float* dbias_part;
+  // RSH (7x3 kernels, three launches of three tap rows): the staged input tile starts ty0 rows below the 7x3 halo corner
+  // (y0 - pad_y, x0 - 1); only the first `nstore` of the nine accumulators are real taps (the last launch has one tap row)
+  int ty0, pad_y, nstore;
   unsigned long long* trace;   // diagnostic builds only (-DOCT_TRACE): s_memtime stamps of workgroup (0,0,0)
 };
 
@@ -76,7 +79,11 @@ __device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* first, const uns
 }
 
 // D3: depth shift of the input tile / image map of an S2D dY (volumetric network) -- compile-time, see igemm2.hip
-template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false>
+// RSH: the nine taps are rows ty0 .. ty0 + 2 of a TALLER kernel (ReLayNet's 7x3, ReLayNet_2017.py:155-160, padding (3, 1)):
+// dW[ty0 + ty][tx] = sum dY[y][x] * A[y - pad_y + ty0 + ty][x - 1 + tx].  Same tile, same loop; the input tile is fetched
+// ty0 - pad_y + 1 rows further down and its rows are checked against the image by range instead of by halo flags (a shifted
+// tile reaches padding on more tile rows than the first and the last).
+template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false, bool RSH = false>
 __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   constexpr int TW = 32;
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -160,18 +167,20 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     const int pw = __builtin_amdgcn_readfirstlane(wave) - 4;   // producer wave 0..3, scalar: the LDS-DMA destination is wave-uniform
     // per-slot constants (shared by all blocks): pixel offset from the tile origin + border code
     int reli[SIB], reld[SDB];
+    int lyv[RSH ? SIB : 1];   // RSH: local row of the slot
     unsigned code[SIB], dcode[SDB];   // bits 8-15 / 16-23: local row / column (ragged last tiles), low bits: halo flags
 #pragma unroll
     for (int j = 0; j < SIB; ++j) {
       const int pix = pb + 64 * j;
       const int ly = pix / LW, lx = pix - ly * LW;
-      reli[j] = ly * p.w + lx;   // relative to the tile's halo corner: never negative (a scalar base + unsigned lane offset per load)
+      reli[j] = (RSH ? ly + p.ty0 : ly) * p.w + lx;   // relative to the tile's halo corner: never negative (a scalar base + unsigned lane offset per load)
+      if constexpr (RSH) lyv[j] = ly;
       // bottom / right flags against the LAST tile row / column of the image (see igemm2.hip): the halo
       // row / column for whole tiles, everything beyond H, W for a ragged size
       const int ylast = p.h - (p.tiles_y - 1) * TH + HALO, xlast = p.w - (p.tiles_x - 1) * TW + HALO;
       unsigned c = pix >= NPI ? 16u : 0u;
-      if (HALO) c |= (ly == 0 ? 1u : 0u) | (lx == 0 ? 4u : 0u);
-      c |= (ly >= ylast ? 2u : 0u) | (lx >= xlast ? 8u : 0u);
+      if (HALO) c |= ((!RSH && ly == 0) ? 1u : 0u) | (lx == 0 ? 4u : 0u);
+      c |= ((!RSH && ly >= ylast) ? 2u : 0u) | (lx >= xlast ? 8u : 0u);
       code[j] = c | (SWZ ? (unsigned)(((lx >> 3) & 1) << 1) << 8 : 0u);   // bits 8-9: chunk swizzle of this pixel
     }
     unsigned dswz[SDB];
@@ -191,6 +200,13 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
                             (txi == p.tiles_x - 1 ? 8u : 0u);
       const size_t origin = ((size_t)img * p.h + tyi * TH) * p.w + txi * TW;
       S.img = img; S.tyi = tyi; S.txi = txi;
+      // RSH: local rows [ylo, ylo + ynum) of the shifted tile lie inside the image (row ly is image row y0 - pad_y + ty0 + ly)
+      int ylo = 0; unsigned ynum = 0;
+      if constexpr (RSH) {
+        const int ytop = tyi * TH - p.pad_y + p.ty0;
+        ylo = max(0, -ytop);
+        ynum = (unsigned)max(0, min(LH, p.h - ytop) - ylo);
+      }
       // 3-D: the input tile of this depth tap lies one slice up / down; outside the volume it is padding (the loads
       // then re-read the tile's own slice and every slot is marked dead)
       bool zok = true;
@@ -210,13 +226,15 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         // 64-bit address arithmetic this replaces was 4-5 vector instructions per load, 20 loads per stage, on the waves
         // the stage waits for (producers 5.76 k cycles against 5.35 k of MFMA phase, profiles/r02_wgrad2_timeline.txt)
         const bf16_t* base = second ? p.x1 + in_origin * p.c1 + (cg - p.c0) : p.x0 + in_origin * p.c0 + cg;
-        const unsigned cs2 = 2u * (unsigned)cs, safe = (unsigned)(HALO * (p.w + 1)) * cs2 + (unsigned)g * 16u;
-        const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - (size_t)(HALO * (p.w + 1)) * cs2;
+        const unsigned corner = RSH ? (unsigned)(p.pad_y * p.w + HALO) : (unsigned)(HALO * (p.w + 1));   // pixels from the halo corner to the tile origin
+        const unsigned cs2 = 2u * (unsigned)cs, safe = corner * cs2 + (unsigned)g * 16u;
+        const unsigned char* const hb = reinterpret_cast<const unsigned char*>(base) - (size_t)corner * cs2;
         // unconditional loads (see igemm2.hip): invalid slots re-read the tile origin, zeroed at commit
         unsigned vm = 0;
 #pragma unroll
         for (int j = 0; j < SIB; ++j) {
-          const bool ok = (!D3 || zok) && (code[j] & edge) == 0;
+          bool ok = (!D3 || zok) && (code[j] & edge) == 0;
+          if constexpr (RSH) ok = ok && (unsigned)(lyv[j] - ylo) < ynum;   // image rows only
           S.ri[blk][j] = *reinterpret_cast<const u32x4*>(hb + (ok ? __umul24((unsigned)reli[j], cs2) + (unsigned)g * 16u : safe));
           vm |= ok ? (1u << j) : 0u;
         }
@@ -562,7 +580,8 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     }
   } else {
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < TAPS; ++t) {
+    if (RSH && t >= p.nstore) continue;   // the tap rows beyond the kernel (last launch of a 7x3: one row of three)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       // W16: register 4S + e, S = 2a + b -> (co 16a + 4*(lane>>4) + e, ci 16b + (lane&15))
@@ -571,6 +590,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       float* const q = &out[((size_t)t * p.cout + co) * p.ktot + ci];
       if (p.part_mode) *q = acc[t][i]; else atomicAdd(q, acc[t][i]);
     }
+  }
   if (do_bias && (W16 ? li == 0 : r == 0)) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -593,14 +613,14 @@ static bool w2_enabled() {
   return on == 1;
 }
 
-template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false>
+template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false, bool RSH = false>
 static void launch_w2r(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   constexpr int halo = TAPS == 9 ? 1 : 0;
   constexpr int stage = IB * (TH + 2 * halo) * (32 + 2 * halo) * 64 + CB * TH * 32 * 64;
   constexpr int lds = 2 * stage + 2 * 32 * IB * (int)sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<TAPS, CB, IB, TH, RAGGED, D3>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<TAPS, CB, IB, TH, RAGGED, D3, RSH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
@@ -613,7 +633,7 @@ static void launch_w2r(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
   p.interleave = p.ntiles >= 2 * gx ? 1 : 0;
   if (!p.interleave) gx = (p.ntiles + p.per_wg - 1) / p.per_wg;
   if (p.part_mode < 0) { p.part_mode = gx * (CB * IB > 4 ? 1 : 4 / (CB * IB)); return; }   // query: slabs this launch would write
-  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH, RAGGED, D3>), dim3(gx, gy, gz), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((wgrad2_kernel<TAPS, CB, IB, TH, RAGGED, D3, RSH>), dim3(gx, gy, gz), dim3(512), lds, s, p);
 }
 template <int TAPS, int CB, int IB, int TH>
 static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
@@ -628,7 +648,12 @@ static void launch_w2(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
 // of partial slabs the launch would write in partials mode
 int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query) {
   if (!w2_enabled()) return 0;
-  if (d->kh == 7) return 0;   // 7x3: generic kernel
+  if (d->kh == 7) {
+    // 7x3 (ReLayNet): 64 x 64 channel blocks, atomics mode only; everything else stays on the generic kernel
+    if (d->taps != 21 || d->kw != 3 || d->depth > 0 || d->dy_img_mul != 0 || d->dy_mode != OCT_IN_PLAIN || d->partials ||
+        d->dtype != OCT_DT_BF16 || (d->c0 % 32) != 0 || (d->c1 % 32) != 0 || (d->cout % 64) != 0 || ((d->c0 + d->c1) % 64) != 0)
+      return 0;
+  }
   if ((d->depth > 0 || d->dy_img_mul != 0) && ((d->w % 32) != 0 || (d->h % 16) != 0)) return 0;   // volumetric: whole tiles
   const int ktot = d->c0 + d->c1;
   // plain 3x3 / 1x1: any H, W (ragged last tiles are predicated); the deconv mode needs whole tiles
@@ -657,7 +682,21 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
   const int nco = d->cout / 32, nci = ktot / 32;
   const bool big = (nco % 2 == 0) && (nci % 2 == 0);
   hipStream_t s = as_stream(stream);
-  if (d->taps == 9) {
+  p.ty0 = 0; p.pad_y = 1; p.nstore = 9;
+  if (d->kh == 7) {
+    // three launches of three tap rows each (rows 0-2, 3-5, 6 + two rows beyond the kernel whose accumulators are dropped:
+    // 27 taps of MFMA work for 21); the bias gradient rides on the first
+    const bool whole = (p.w % 32) == 0 && (p.h % 8) == 0;
+    float* const dwp0 = p.dwp;
+    for (int ty0 = 0; ty0 < 7; ty0 += 3) {
+      p.ty0 = ty0; p.pad_y = 3; p.nstore = ty0 == 6 ? 3 : 9;
+      p.dwp = dwp0 + (size_t)ty0 * 3 * d->cout * ktot;
+      if (ty0 > 0) p.dbias = nullptr;
+      if (whole) launch_w2r<9, 2, 2, 8, false, false, true>(p, nco, nci, s);
+      else launch_w2r<9, 2, 2, 8, true, false, true>(p, nco, nci, s);
+      if (query) break;
+    }
+  } else if (d->taps == 9) {
     // 64 x 64 channel blocks: 8-row tiles (halo overhead 10/8 instead of 6/4 on the staged input, half the
     // barriers; the two 76-KB stage buffers fill the LDS and the producer ring drops to 2 stages): -5 %
     // 32 x 32 channel blocks (the 32-channel full-resolution layers): 16-row tiles, halo overhead 18/16 -- -6 %

@@ -303,7 +303,11 @@ def test_conv3x3_wgrad_with_fused_bias_gradient_bit_exact(env, shape):
     same(db.cpu().numpy(), dy.astype(np.float64).sum(axis=(0, 2, 3)), "bias gradient")
 
 
-KK73 = [(2, 16, 32, 32, 0, 32), (1, 14, 40, 64, 0, 64), (1, 16, 32, 64, 64, 64), (2, 9, 24, 32, 0, 96)]
+# the 64 / 128-channel-block shapes run on the pipelined kernels (igemm2 TAPS = 21: three halo rows; wgrad2: three row-shifted
+# launches), the others on the generic ones: several tile rows (interior tiles), ragged heights with 4 and 6 rows left,
+# ragged widths, concat sources, whole tiles (LDS-DMA data gradient), and a height the pipelined kernels refuse (9 = 8 + 1)
+KK73 = [(2, 16, 32, 32, 0, 32), (1, 14, 40, 64, 0, 64), (1, 16, 32, 64, 64, 64), (2, 9, 24, 32, 0, 96),
+        (1, 40, 64, 64, 0, 64), (1, 30, 64, 64, 64, 64), (2, 24, 64, 128, 0, 128), (1, 20, 40, 64, 0, 64), (1, 17, 32, 64, 0, 64)]
 
 
 @pytest.mark.parametrize("shape", KK73)
