@@ -214,11 +214,15 @@ __global__ void __launch_bounds__(256) first_fprop_kernel(const bf16_t* __restri
 // row and slice validity are wave-uniform, only the two end lanes of a row test x -- packs them into the B fragment and one
 // (two) MFMA per 32 output channels replace 9,216 (27,648) FMAs; the epilogue is igemm2's (bf16 pack, wave-private LDS
 // transpose, 16-byte NHWC stores, BatchNorm sums in registers).
+// KD = 7: not a depth count but ReLayNet's 7x3 kernel (ReLayNet_2017.py:155-160, padding (3, 1)): 21 taps T = kh*3 + kw, two k16
+// steps, tap rows -3 .. +3 (f1_ntap / f1_dy / f1_pady below; the packed filter is [cout/32][21][512], see oct_pack_weights_kk)
+template <int KD> constexpr int f1_ntap() { return KD == 7 ? 21 : 9 * KD; }
+template <int KD> constexpr int f1_pady() { return KD == 7 ? 3 : 1; }
 template <int F, int KD>
 __global__ void __launch_bounds__(256) first_fprop_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
                                                                bf16_t* __restrict__ y, float* __restrict__ stats, int n,
                                                                int h, int w, int depth) {
-  constexpr int NTAP = 9 * KD, KS = (NTAP + 15) / 16, NB = F / 32, NV = 8 * KS;
+  constexpr int NTAP = f1_ntap<KD>(), PADY = f1_pady<KD>(), KS = (NTAP + 15) / 16, NB = F / 32, NV = 8 * KS;
   typedef Mma<bf16_t> M;
   __shared__ __attribute__((aligned(16))) unsigned char scr[4][32 * 80];
   __shared__ float red[4][2][F];
@@ -235,19 +239,20 @@ __global__ void __launch_bounds__(256) first_fprop_mfma_kernel(const bf16_t* __r
       for (int j = 0; j < 8; ++j) {
         const int T = 16 * ks + 8 * hh + j;
         const int kd = T / 9, t = T - 9 * kd;
-        afr[cb][ks][j] = T < NTAP ? wp[(cb * 9 + t) * 512 + r * 8 + (KD == 3 ? kd : 0)] : (bf16_t)0.0f;
+        if (KD == 7) afr[cb][ks][j] = T < NTAP ? wp[(cb * NTAP + T) * 512 + r * 8] : (bf16_t)0.0f;
+        else afr[cb][ks][j] = T < NTAP ? wp[(cb * 9 + t) * 512 + r * 8 + (KD == 3 ? kd : 0)] : (bf16_t)0.0f;
       }
   // this lane's taps: element offset from the pixel and the (dz, dy, dx) class of each
   int toff[NV];
-  unsigned tcls[NV];   // bits 0-1 dz+1, 2-3 dy+1, 4-5 dx+1, bit 6 dead (zero padding of K)
+  unsigned tcls[NV];   // bits 0-1 dz+1, 2-4 dy+PADY, 5-6 dx+1, bit 7 dead (zero padding of K)
   const int plane = h * w;
 #pragma unroll
   for (int jj = 0; jj < NV; ++jj) {
     const int T = 16 * (jj / 8) + 8 * hh + (jj % 8);
     const int kd = T / 9, t = T - 9 * kd;
-    const int dz = KD == 3 ? kd - 1 : 0, dy = t / 3 - 1, dx = t % 3 - 1;
+    const int dz = KD == 3 ? kd - 1 : 0, dy = KD == 7 ? T / 3 - 3 : t / 3 - 1, dx = (KD == 7 ? T : t) % 3 - 1;
     toff[jj] = dz * plane + dy * w + dx;
-    tcls[jj] = T < NTAP ? (unsigned)((dz + 1) | ((dy + 1) << 2) | ((dx + 1) << 4)) : 64u;
+    tcls[jj] = T < NTAP ? (unsigned)((dz + 1) | ((dy + PADY) << 2) | ((dx + 1) << 5)) : 128u;
   }
   float s1[NB][16], s2[NB][16];
 #pragma unroll
@@ -263,14 +268,16 @@ __global__ void __launch_bounds__(256) first_fprop_mfma_kernel(const bf16_t* __r
     const int zz = KD == 3 ? (int)((row / (unsigned)h) % (unsigned)depth) : 0;
     // validity masks, bit c = class c valid: slice and row wave-uniform, column per lane
     const unsigned zm = KD == 3 ? ((zz > 0 ? 1u : 0u) | 2u | (zz + 1 < depth ? 4u : 0u)) : 2u;
-    const unsigned ym = (yy > 0 ? 1u : 0u) | 2u | (yy + 1 < h ? 4u : 0u);
+    unsigned ym = 0;   // bit c: row yy + c - PADY lies in the image
+#pragma unroll
+    for (int c = 0; c <= 2 * PADY; ++c) ym |= (yy + c - PADY >= 0 && yy + c - PADY < h) ? (1u << c) : 0u;
     const int xx = x0 + r;
     const unsigned xm = (xx > 0 ? 1u : 0u) | 2u | (xx + 1 < w ? 4u : 0u);
     const unsigned q = q0 + (unsigned)r;
 #pragma unroll
     for (int jj = 0; jj < NV; ++jj) {
       const unsigned c = tcls[jj];
-      const bool ok = (c & 64u) == 0 && ((zm >> (c & 3u)) & (ym >> ((c >> 2) & 3u)) & (xm >> ((c >> 4) & 3u)) & 1u) != 0;
+      const bool ok = (c & 128u) == 0 && ((zm >> (c & 3u)) & (ym >> ((c >> 2) & 7u)) & (xm >> ((c >> 5) & 3u)) & 1u) != 0;
       const unsigned short val = reinterpret_cast<const unsigned short*>(x)[ok ? (int)q + toff[jj] : (int)q];
       v[jj] = ok ? val : (unsigned short)0;
     }
@@ -450,7 +457,7 @@ __global__ void __launch_bounds__(256) first_wgrad_mfma_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ yraw, const float* __restrict__ coef,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                int part_mode, int depth) {
-  constexpr int NTAP = 9 * KD;
+  constexpr int NTAP = f1_ntap<KD>();   // KD = 7: the 7x3 kernel (see first_fprop_mfma_kernel), dwp = [21][cout]
   constexpr int NB = F / 32, CPP = F / 8, NCH = (32 * CPP) / 64;   // 16-B chunks per pixel / per lane and tensor
   typedef Mma<bf16_t> M;
   __shared__ __attribute__((aligned(16))) unsigned char tile[4][NB][32 * 64];
@@ -473,7 +480,8 @@ __global__ void __launch_bounds__(256) first_wgrad_mfma_kernel(const bf16_t* __r
   const bf16_t* ysrc = coef ? yraw : dy;
   // tap of this lane
   const int t9 = T % 9;
-  const int tdz = (KD == 3 && T < NTAP) ? T / 9 - 1 : 0, tdy = T < NTAP ? t9 / 3 - 1 : 0, tdx = T < NTAP ? t9 % 3 - 1 : 0;
+  const int tdz = (KD == 3 && T < NTAP) ? T / 9 - 1 : 0, tdy = T < NTAP ? (KD == 7 ? T / 3 - 3 : t9 / 3 - 1) : 0,
+            tdx = T < NTAP ? (KD == 7 ? T % 3 : t9 % 3) - 1 : 0;
   const int toff = tdz * h * w + tdy * w + tdx;
   f32x16 acc[NB];
 #pragma unroll
@@ -498,7 +506,7 @@ __global__ void __launch_bounds__(256) first_wgrad_mfma_kernel(const bf16_t* __r
     const unsigned row = q0 / (unsigned)w;
     const int x0 = (int)(q0 - row * (unsigned)w), yy = (int)(row % (unsigned)h);
     const int zz = KD == 3 ? (int)((row / (unsigned)h) % (unsigned)depth) : 0;
-    const bool ok = T < NTAP && (tdy < 0 ? yy > 0 : (tdy > 0 ? yy + 1 < h : true)) &&
+    const bool ok = T < NTAP && yy + tdy >= 0 && yy + tdy < h &&
                     (tdz < 0 ? zz > 0 : (tdz > 0 ? zz + 1 < depth : true));
     vmask = ok ? 0xffffffffu : 0u;
     // the only pixels of a 32-pixel row segment whose x neighbour can leave the image: the first (dx = -1) and the last (dx = +1)
@@ -586,6 +594,16 @@ static bool f1_enabled() {
 static bool first_ok(int dtype, int c0, int c1, int cout, int taps) {
   return f1_enabled() && dtype == OCT_DT_BF16 && c0 == 1 && c1 == 0 && taps == 9 && (cout == 16 || cout == 32 || cout == 64);
 }
+static bool first_mfma_enabled() {
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("OCT_FIRST_MFMA"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
+  return use_mfma == 1;
+}
+// ReLayNet's first layer, Conv2d(1 -> F, 7x3): the matrix-pipe kernels only (W % 32 == 0, F = 32 or 64)
+static bool first73_ok(int dtype, int c0, int c1, int cout, int taps, int kh, int kw, int w, int depth, size_t npix) {
+  return f1_enabled() && first_mfma_enabled() && dtype == OCT_DT_BF16 && c0 == 1 && c1 == 0 && taps == 21 && kh == 7 && kw == 3 &&
+         (cout == 32 || cout == 64) && (w % 32) == 0 && depth == 0 && npix < (1ull << 31);
+}
 static int first_grid(const OctConvDesc* d) {
   const size_t work = (size_t)d->n * d->h * d->w * (d->cout / 8);   // a thread per (pixel, 8-channel group)
   size_t b = (work + 255) / 256;
@@ -594,7 +612,9 @@ static int first_grid(const OctConvDesc* d) {
 }
 
 int oct_first_stat_rows(const OctConvDesc* d) {
-  if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->in_mode || d->out_mode || d->xform0 || d->split) return -1;
+  const bool k73 = first73_ok(d->dtype, d->c0, d->c1, d->cout, d->taps, d->kh, d->kw, d->w, d->depth, (size_t)d->n * d->h * d->w);
+  if (d->kh == 7 && !k73) return -1;
+  if ((!k73 && !first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps)) || d->in_mode || d->out_mode || d->xform0 || d->split) return -1;
   return first_grid(d);
 }
 
@@ -609,7 +629,8 @@ int oct_first_fprop(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
     // matrix-pipe kernel: a wave per 32 consecutive pixels of a row
 #define LAUNCHM(F, KD) hipLaunchKernelGGL((first_fprop_mfma_kernel<F, KD>), dim3(grid), dim3(256), 0, s, (const bf16_t*)a->x0, \
                                           (const bf16_t*)a->wpacked, (bf16_t*)a->y0, st, d->n, d->h, d->w, d->depth)
-    if (d->depth > 0) { if (d->cout == 32) LAUNCHM(32, 3); else LAUNCHM(64, 3); }
+    if (d->kh == 7) { if (d->cout == 32) LAUNCHM(32, 7); else LAUNCHM(64, 7); }
+    else if (d->depth > 0) { if (d->cout == 32) LAUNCHM(32, 3); else LAUNCHM(64, 3); }
     else { if (d->cout == 32) LAUNCHM(32, 1); else LAUNCHM(64, 1); }
 #undef LAUNCHM
     int rcm = oct_check_launch("first_fprop_mfma");
@@ -652,7 +673,9 @@ extern "C" int oct_conv_wgrad_all_depth_taps_ok(const OctWgradDesc* d) {
 }
 
 int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query) {
-  if (!first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps) || d->xform0 || d->dy_mode) return 0;
+  const bool k73 = first73_ok(d->dtype, d->c0, d->c1, d->cout, d->taps, d->kh, d->kw, d->w, d->depth, (size_t)d->n * d->h * d->w);
+  if (d->kh == 7 && (!k73 || (!query && a->dy_coef))) return 0;
+  if ((!k73 && !first_ok(d->dtype, d->c0, d->c1, d->cout, d->taps)) || d->xform0 || d->dy_mode) return 0;
   if (!query && a->dbias) return 0;   // no bias-gradient path in the direct kernel: the MFMA kernels take it
   if (!query && a->dy_coef && (!a->dy_y || !a->dy_scale || !a->dy_shift)) { oct_set_error("oct_conv_wgrad: fused apply needs y, scale, shift"); return OCT_E_INVALID; }
   const size_t total = (size_t)d->n * d->h * d->w * (d->cout / 8);
@@ -669,7 +692,8 @@ int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, 
 #define LAUNCHM(F, KD) hipLaunchKernelGGL((first_wgrad_mfma_kernel<F, KD>), dim3((int)b), dim3(256), 0, s, (const bf16_t*)a->x0, \
                                           (const bf16_t*)a->dy, a->dwp, d->n, d->h, d->w, \
                                           (const bf16_t*)a->dy_y, a->dy_coef, a->dy_scale, a->dy_shift, part_mode, d->depth)
-    if (all_taps) { if (d->cout == 32) LAUNCHM(32, 3); else LAUNCHM(64, 3); }
+    if (k73) { if (d->cout == 32) LAUNCHM(32, 7); else LAUNCHM(64, 7); }
+    else if (all_taps) { if (d->cout == 32) LAUNCHM(32, 3); else LAUNCHM(64, 3); }
     else { if (d->cout == 32) LAUNCHM(32, 1); else LAUNCHM(64, 1); }
 #undef LAUNCHM
     int rcm = oct_check_launch("first_wgrad_mfma");

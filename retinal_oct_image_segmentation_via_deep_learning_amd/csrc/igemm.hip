@@ -486,7 +486,7 @@ static TileCfg pick_cfg(int cout) {
 extern "C" int oct_conv_stat_blocks(const OctConvDesc* d) {
   if (!d) return 0;
   {
-    const int f1 = d->kh != 7 ? oct_first_stat_rows(d) : -1;   // the 1 -> F first-layer kernels are 3x3
+    const int f1 = oct_first_stat_rows(d);
     if (f1 >= 0) return f1;
     const int v2 = oct_conv_v2_stat_rows(d);
     if (v2 >= 0) return v2;
@@ -555,7 +555,7 @@ extern "C" int oct_conv_forward(const OctConvDesc* d, const OctConvArgs* a, void
   OCT_CHECK(!(d->want_stats && !a->stat_partials), "oct_conv_forward: want_stats without buffer");
   OCT_CHECK((size_t)d->n * d->h * d->w < (1u << 31), "oct_conv_forward: too many pixels");
   {
-    int took = kh != 7 ? oct_first_fprop(d, a, stream) : 0;
+    int took = oct_first_fprop(d, a, stream);
     if (took == 0) took = oct_conv_forward_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
   }

@@ -231,7 +231,8 @@ extern "C" int oct_conv_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void
     if (took == 0) took = oct_conv_wgrad_v2(d, a, stream);
     if (took != 0) return took < 0 ? took : OCT_OK;
   } else {
-    const int took = oct_conv_wgrad_v2(d, a, stream);   // 64-channel-block shapes: three row-shifted launches of the 3x3 kernel
+    int took = oct_first_wgrad(d, a, stream);            // Conv2d(1 -> F, 7x3): the matrix-pipe first-layer kernel
+    if (took == 0) took = oct_conv_wgrad_v2(d, a, stream);   // 64-channel-block shapes: three row-shifted launches of the 3x3 kernel
     if (took != 0) return took < 0 ? took : OCT_OK;
   }
   WgradParams p;
@@ -289,7 +290,10 @@ extern "C" int oct_conv_wgrad_partials(const OctWgradDesc* d) {
   if (kh != 7) {
     if (oct_first_wgrad(d, nullptr, nullptr, &q) == 1) return q;
     if (oct_conv_wgrad_v2(d, nullptr, nullptr, &q) == 1) return q;
-  } else if (oct_conv_wgrad_v2(d, nullptr, nullptr, &q) == 1) return q;
+  } else {
+    if (oct_first_wgrad(d, nullptr, nullptr, &q) == 1) return q;
+    if (oct_conv_wgrad_v2(d, nullptr, nullptr, &q) == 1) return q;
+  }
   const int ktot = d->c0 + d->c1;
   const int nco = ceil_div(d->cout, 32), nci = ceil_div(ktot, 32);
   const int ntiles = ceil_div(d->w, 32) * ceil_div(d->h, 8) * d->n;

@@ -353,3 +353,37 @@ def test_conv7x3_fprop_dgrad_wgrad_bit_exact(env, shape):
                                      padding=(3, 1)).numpy()
     assert np.abs(dw).max() * 2 < 2 ** 23
     same(grad.cpu().numpy(), dw, "7x3 wgrad")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 64, 64), (1, 21, 32, 32), (3, 5, 96, 64), (1, 12, 40, 64)])
+def test_conv7x3_first_layer_bit_exact(env, shape):
+    """ReLayNet's first convolution, Conv2d(1 -> F, 7x3) (ReLayNet_2017.py:155-160 with in_channels = 1): forward (with the
+    BatchNorm sums) and weight gradient on the matrix-pipe first-layer kernels (first.hip, KD = 7: 21 taps in two k16 steps) for
+    W % 32 == 0, on the generic kernels otherwise (last shape) -- bit equality against torch's float64 convolution.  Heights
+    below, at and above the seven tap rows."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    L, E = env
+    n, h, w, cout = shape
+    rng = np.random.default_rng(abs(hash(shape)) % 2**32 + 731)
+    eng = ops.kernels("bf16")
+    src, eff = exact_src(E, rng, n, h, w, 1, 0, False)
+    wt = pow2_weights(rng, (cout, 1, 7, 3), density=0.7)
+    wd = fdev(wt)
+    kk = dict(kh=7, kw=3)
+    wp = ops.packed(eng, wd, L.PACK_CONV_FPROP, cout, 1, cache=False, kk=(7, 3))
+    y = torch.full((n, h, w, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    part = torch.full((eng._stat_blocks(cout, n, h, w, src, 21, **kk), 2, cout), float("nan"), dtype=torch.float32, device="cuda")
+    eng._conv(src, wp, cout, 21, n, h, w, y, stats=part, **kk)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(eff).double(), torch.from_numpy(wt).double(), padding=(3, 1)).numpy()
+    same(host(y), to_bf16(ref), "7x3 first-layer fprop")
+    np.testing.assert_allclose(part.double().sum(0).cpu().numpy()[0], ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(part.double().sum(0).cpu().numpy()[1], (ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-2)
+    dy = ints(rng, (n, cout, h, w), -2, 2) * (rng.random((n, cout, h, w)) < 0.5)
+    dwp = eng._wgrad(src, dev(dy), cout, 21, n, h, w, partials_ok=False, **kk)
+    grad = torch.full((cout, 1, 7, 3), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(L.lib().oct_unpack_wgrad_kk(dwp.data_ptr(), grad.data_ptr(), cout, 1, 7, 3, 0, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    dw = torch.nn.grad.conv2d_weight(torch.from_numpy(eff).double(), (cout, 1, 7, 3), torch.from_numpy(dy.astype(np.float64)),
+                                     padding=(3, 1)).numpy()
+    assert np.abs(dw).max() * 2 < 2 ** 23
+    same(grad.cpu().numpy(), dw, "7x3 first-layer wgrad")
