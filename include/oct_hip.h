@@ -264,9 +264,9 @@ int oct_bn_bwd_apply(int dtype, void* g, const void* y, const float* coef, const
 int oct_bn_bwd_apply_to(int dtype, void* dst, const void* g, const void* y, const float* coef, const float* scale,
                         const float* shift, size_t npix, int c, void* stream);
 /* ------------------------------------------------------------------------------------------
- * 1x1 convolution with k <= 4 output channels: Attention_block's psi = Conv2d(F_int, 1, 1) (SD_Layer_Net/common.py:79-83)
+ * 1x1 convolution with k <= 12 output channels: Attention_block's psi = Conv2d(F_int, 1, 1) (SD_Layer_Net/common.py:79-83)
  * and the heads Conv_1x1 = Conv2d(64, output_ch, 1) (SD_Layer_Net/unet.py:38,113).  Three streaming kernels instead of
- * GEMMs padded k -> 32 (c = 8 * 2^j <= 512, k <= 4: oct_rowdot_ok; other shapes stay on oct_conv_forward / oct_conv_wgrad).
+ * GEMMs padded k -> 32 (c = 8 * 2^j <= 512 with k <= 4, c <= 128 with k = 5..12 -- ReLayNet's / MGU-Net's class heads: oct_rowdot_ok; other shapes stay on oct_conv_forward / oct_conv_wgrad).
  * x, dx: [npix][c] NHWC; y, dy: [npix][k]; w, dw: [k][c] fp32 (torch (k,c,1,1)).
  *   fwd       : y = x . w^T; stats (may be NULL): [oct_rowdot_blocks][2][k] partial sum / sum of squares (oct_bn_finalize rows)
  *   bwd_data  : dx[pix][c] = sum_k dy[pix][k] * w[k][c]

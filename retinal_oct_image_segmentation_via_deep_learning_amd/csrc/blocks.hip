@@ -659,10 +659,14 @@ extern "C" int oct_depth_pool_bwd(int dtype, const void* p2, const void* dout, v
 // replaces; sums are fp32.
 // ---------------------------------------------------------------------------------------------
 #define RD_MAX_BLOCKS 512
-#define RD_MAX_K 4
+// K = 5 .. 12 (the classifier heads of the layer networks: ReLayNet_2017.py:118-126 Conv2d(64, 10, 1), MGUNet_2021's 11 classes)
+// with c <= 128: on the generic MFMA kernels (Cout not a multiple of 32) the three passes of ReLayNet's head took 0.7-0.8 ms
+// each at 496 x 768 x 16, 2.3 of 21.5 ms per step, for 0.13 ms of memory traffic.
+#define RD_MAX_K 12
+#define RD_WIDE_C 128   /* K > 4: the weight-gradient kernel folds its waves through K * c floats of LDS */
 static inline bool rowdot_shape_ok(int c, int k) {
   const int g = c / 8;
-  return c % 8 == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 && k >= 1 && k <= RD_MAX_K;
+  return c % 8 == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 && k >= 1 && k <= RD_MAX_K && (k <= 4 || c <= RD_WIDE_C);
 }
 static inline int rowdot_grid(size_t npix, int c) {
   const size_t ppb = BK_THREADS / (c / 8);
@@ -724,6 +728,55 @@ __global__ void __launch_bounds__(BK_THREADS) rowdot_fwd_kernel(const T* __restr
     if (threadIdx.x < 2 * K) {
       const int st = threadIdx.x / K, k = threadIdx.x % K;
       stats[((size_t)blockIdx.x * 2 + st) * K + k] = red[st][k][0] + red[st][k][1] + red[st][k][2] + red[st][k][3];
+    }
+  }
+}
+
+// Forward for K = 5 .. 12 classes in bf16 without statistics (the class heads) on the matrix pipe: per 16 pixels one
+// v_mfma_f32_16x16x32_bf16 per 32 input channels, D[row = class][col = pixel].  The B operand is the NHWC tensor as it lies in
+// memory (lane (pixel l & 15, k quarter l >> 4) loads the 16 B of channels 8 * (l >> 4) ..+7 of its pixel), the A operand the
+// bf16-rounded filter with rows >= K zero.  The shuffle kernel above closes every one of the K dot products with log2(c / 8)
+// cross-lane steps and lets one lane in c / 8 store 2-byte values: at K = 10, c = 64 it took 1.12 ms for ReLayNet's head at
+// 496 x 768 x 16 (0.9 GB of traffic), slower than the padded GEMM it replaced.
+template <int K>
+__global__ void __launch_bounds__(256) rowdot_fwd_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                              bf16_t* __restrict__ y, size_t npix, int c) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int nkc = c >> 5;   // 32-channel steps: 1, 2 or 4 (checked by the host)
+  bf16x8 afr[4];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      afr[kc][j] = (kc < nkc && r16 < K) ? (bf16_t)w[(size_t)r16 * c + kc * 32 + kq * 8 + j] : (bf16_t)0.0f;
+  const size_t ngroups = (npix + 15) >> 4, gstride = (size_t)gridDim.x * 4;
+  for (size_t g = (size_t)blockIdx.x * 4 + wave; g < ngroups; g += gstride) {
+    const size_t pix = g * 16 + r16;
+    const bool in = pix < npix;
+    const bf16_t* xp = x + (in ? pix : npix - 1) * c + kq * 8;
+    bf16x8 b[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+      if (kc < nkc) b[kc] = *reinterpret_cast<const bf16x8*>(xp + kc * 32);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+      if (kc < nkc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[kc], b[kc], acc, 0, 0, 0);
+    if (!in) continue;
+    bf16_t* const yp = y + pix * K + 4 * kq;   // classes 4 * kq ..+3 of this pixel
+    if constexpr ((K & 1) == 0) {              // even K: the pixel's row is 4-byte aligned, pairs leave as one dword
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int e = 0; e < 4; e += 2)
+        if (4 * kq + e < K) {
+          bf16x2 v; v[0] = (bf16_t)acc[e]; v[1] = (bf16_t)acc[e + 1];
+          *reinterpret_cast<bf16x2*>(yp + e) = v;
+        }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * kq + e < K) yp[e] = (bf16_t)acc[e];
     }
   }
 }
@@ -791,7 +844,7 @@ __global__ void __launch_bounds__(BK_THREADS) rowdot_bwd_weight_kernel(const T* 
     }
   }
   // lanes gi, gi + G, gi + 2G ... of a wave own the same channels: fold them, then the four waves through LDS
-  __shared__ float red[BK_THREADS / 64][K * 512];
+  __shared__ float red[BK_THREADS / 64][K * (K > 4 ? RD_WIDE_C : 512)];
 #pragma unroll
   for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -827,14 +880,31 @@ __global__ void __launch_bounds__(256) rowdot_bwd_weight_sum_kernel(const float*
     if (k == 1) hipLaunchKernelGGL((KERNEL<T, 1>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);               \
     else if (k == 2) hipLaunchKernelGGL((KERNEL<T, 2>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
     else if (k == 3) hipLaunchKernelGGL((KERNEL<T, 3>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
-    else hipLaunchKernelGGL((KERNEL<T, 4>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);                      \
+    else if (k == 4) hipLaunchKernelGGL((KERNEL<T, 4>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
+    else if (k == 5) hipLaunchKernelGGL((KERNEL<T, 5>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
+    else if (k == 6) hipLaunchKernelGGL((KERNEL<T, 6>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
+    else if (k == 7) hipLaunchKernelGGL((KERNEL<T, 7>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
+    else if (k == 8) hipLaunchKernelGGL((KERNEL<T, 8>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
+    else if (k == 9) hipLaunchKernelGGL((KERNEL<T, 9>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);          \
+    else if (k == 10) hipLaunchKernelGGL((KERNEL<T, 10>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);        \
+    else if (k == 11) hipLaunchKernelGGL((KERNEL<T, 11>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);        \
+    else hipLaunchKernelGGL((KERNEL<T, 12>), dim3(grid), dim3(BK_THREADS), 0, s, __VA_ARGS__);                     \
   } while (0)
 
 extern "C" int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y, float* stats, size_t npix, int c, int k, void* stream) {
   OCT_CHECK(x && w && y && npix > 0, "oct_rowdot_fwd: bad args");
-  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_fwd: c = %d must be 8 * 2^j <= 512 and k = %d in 1..4 (ask oct_rowdot_ok)", c, k);
+  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_fwd: c = %d must be 8 * 2^j <= 512 and k = %d in 1..12 (k > 4: c <= 128; ask oct_rowdot_ok)", c, k);
   const int grid = rowdot_grid(npix, c);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == OCT_DT_BF16 && k > 4 && !stats && (c % 32) == 0) {   // class heads: the matrix-pipe kernel
+    size_t gb = ((npix + 15) / 16 + 3) / 4;
+    if (gb > 2048) gb = 2048;   // eight waves per SIMD
+#define RDM(KK) hipLaunchKernelGGL((rowdot_fwd_mfma_kernel<KK>), dim3((int)gb), dim3(256), 0, s, (const bf16_t*)x, w, (bf16_t*)y, npix, c)
+    switch (k) { case 5: RDM(5); break; case 6: RDM(6); break; case 7: RDM(7); break; case 8: RDM(8); break; case 9: RDM(9); break;
+                 case 10: RDM(10); break; case 11: RDM(11); break; default: RDM(12); break; }
+#undef RDM
+    return oct_check_launch("rowdot_fwd_mfma");
+  }
   if (dtype == OCT_DT_BF16) RD_LAUNCH(rowdot_fwd_kernel, bf16_t, (const bf16_t*)x, w, (bf16_t*)y, stats, npix, c);
   else if (dtype == OCT_DT_F32) RD_LAUNCH(rowdot_fwd_kernel, float, (const float*)x, w, (float*)y, stats, npix, c);
   else OCT_CHECK(false, "oct_rowdot_fwd: bad dtype");
@@ -842,7 +912,7 @@ extern "C" int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y,
 }
 extern "C" int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, void* dx, size_t npix, int c, int k, void* stream) {
   OCT_CHECK(dy && w && dx && npix > 0, "oct_rowdot_bwd_data: bad args");
-  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_bwd_data: c = %d must be 8 * 2^j <= 512 and k = %d in 1..4", c, k);
+  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_bwd_data: c = %d must be 8 * 2^j <= 512 and k = %d in 1..12 (k > 4: c <= 128)", c, k);
   const int grid = rowdot_grid(npix, c);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OCT_DT_BF16) RD_LAUNCH(rowdot_bwd_data_kernel, bf16_t, (const bf16_t*)dy, w, (bf16_t*)dx, npix, c);
@@ -853,7 +923,7 @@ extern "C" int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, vo
 extern "C" int oct_rowdot_bwd_weight(int dtype, const void* dy, const void* x, float* dw, float* partials, size_t npix, int c,
                                      int k, int accumulate, void* stream) {
   OCT_CHECK(dy && x && dw && partials && npix > 0, "oct_rowdot_bwd_weight: bad args");
-  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_bwd_weight: c = %d must be 8 * 2^j <= 512 and k = %d in 1..4", c, k);
+  OCT_CHECK(rowdot_shape_ok(c, k), "oct_rowdot_bwd_weight: c = %d must be 8 * 2^j <= 512 and k = %d in 1..12 (k > 4: c <= 128)", c, k);
   const int grid = rowdot_grid(npix, c);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OCT_DT_BF16) RD_LAUNCH(rowdot_bwd_weight_kernel, bf16_t, (const bf16_t*)dy, (const bf16_t*)x, partials, npix, c);

@@ -211,8 +211,11 @@ class ConvAffineAct(torch.autograd.Function):
             raise RuntimeError("a lazy BN + ReLU output needs a train-mode BatchNorm + ReLU without residual")
         if lazy == "affine" and not (bn is None and act == L.ACT_NONE and res is None):
             raise RuntimeError("a lazy affine output is a bare convolution (+ bias)")
-        # 1-4 output channels (Attention_block's psi, the heads): three streaming kernels instead of GEMMs padded to 32 rows
-        rowdot = (taps == 1 and x1 is None and xf0 is None and lib.oct_rowdot_ok(c0, cout) == 1 and not e.rowdot_off)
+        # 1-4 output channels (Attention_block's psi, the heads): three streaming kernels instead of GEMMs padded to 32 rows;
+        # 5-12 only for bare convolutions (the class heads of ReLayNet / MGU-Net): a narrow Attention_block's W_g / W_x
+        # (F_int = 8) keeps the kernel it has in BOTH activation schedules, whose results are compared bit for bit
+        rowdot = (taps == 1 and x1 is None and xf0 is None and lib.oct_rowdot_ok(c0, cout) == 1 and not e.rowdot_off
+                  and (cout <= 4 or bn is None))
         wp = None if rowdot else packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
         y = e._act(n, h, wd, cout, dev)
         scale = torch.empty(cout, dtype=torch.float32, device=dev)

@@ -138,10 +138,10 @@ def test_gate_product_backward_all_channel_paths(dt, tol, c):
 
 
 @pytest.mark.parametrize("dtype,c,k", [("f32", 32, 1), ("bf16", 32, 1), ("bf16", 64, 3), ("f32", 8, 4), ("bf16", 512, 1), ("f32", 64, 2),
-                                       ("bf16", 512, 4)])
+                                       ("bf16", 512, 4), ("bf16", 64, 10), ("f32", 64, 11), ("bf16", 128, 12), ("bf16", 32, 5), ("bf16", 64, 7), ("bf16", 16, 9)])
 def test_rowdot_kernels_match_numpy(dtype, c, k):
-    """oct_rowdot_{fwd,bwd_data,bwd_weight} (1x1 convolutions with 1-4 output channels: Attention_block.psi,
-    common.py:79-83, and the heads Conv_1x1, unet.py:38,113) against numpy on a pixel count that is not a multiple of
+    """oct_rowdot_{fwd,bwd_data,bwd_weight} (1x1 convolutions with 1-12 output channels: Attention_block.psi,
+    common.py:79-83, the heads Conv_1x1, unet.py:38,113, ReLayNet's 10-class classifier, ReLayNet_2017.py:118-126) against numpy on a pixel count that is not a multiple of
     anything; integer-valued operands make every product and sum exact, so the comparison is bit-for-bit."""
     from retinal_oct_image_segmentation_via_deep_learning_amd import _lib as L
     lib = L.lib()
@@ -153,7 +153,7 @@ def test_rowdot_kernels_match_numpy(dtype, c, k):
     w = (rng.integers(-1, 2, (k, c)) * (rng.random((k, c)) < 64.0 / c)).astype(np.float32)   # |y| <= 64-ish: exact in bf16
     dy = rng.integers(-2, 3, (npix, k)).astype(np.float32)
     X, W, DY = torch.from_numpy(x).to("cuda", tdt), torch.from_numpy(w).cuda(), torch.from_numpy(dy).to("cuda", tdt)
-    assert lib.oct_rowdot_ok(c, k) == 1 and lib.oct_rowdot_ok(24, 1) == 0 and lib.oct_rowdot_ok(1024, 1) == 0 and lib.oct_rowdot_ok(64, 5) == 0
+    assert lib.oct_rowdot_ok(c, k) == 1 and lib.oct_rowdot_ok(24, 1) == 0 and lib.oct_rowdot_ok(1024, 1) == 0 and lib.oct_rowdot_ok(64, 13) == 0 and lib.oct_rowdot_ok(256, 5) == 0
     nblk = lib.oct_rowdot_blocks(npix, c)
     Y = torch.empty((npix, k), dtype=tdt, device="cuda")
     ST = torch.empty((nblk, 2, k), dtype=torch.float32, device="cuda")
@@ -164,6 +164,10 @@ def test_rowdot_kernels_match_numpy(dtype, c, k):
     assert np.array_equal(Y.float().cpu().numpy(), y)
     s = ST.sum(0).cpu().numpy()
     assert np.array_equal(s[0], y.sum(0)) and np.array_equal(s[1], (y * y).sum(0))
+    # without statistics (a class head): 5-12 classes in bf16 with c % 32 == 0 take the matrix-pipe forward kernel
+    Y2 = torch.full((npix, k), float("nan"), dtype=tdt, device="cuda")
+    L.check(lib.oct_rowdot_fwd(dt, X.data_ptr(), W.data_ptr(), Y2.data_ptr(), None, npix, c, k, st))
+    assert np.array_equal(Y2.float().cpu().numpy(), y)
     DX = torch.empty_like(X)
     L.check(lib.oct_rowdot_bwd_data(dt, DY.data_ptr(), W.data_ptr(), DX.data_ptr(), npix, c, k, st))
     assert np.array_equal(DX.float().cpu().numpy(), dy @ w)
