@@ -47,13 +47,36 @@ class UnetUp4(UnetUp):
     K = 4
 
 
+# Dropout2d (common.py:13,17,34) under a FIXED mask: tests set DROPOUT_MASKS to the keep flags the fixture recorded ([n, c] each, in
+# forward order); None is torch's own random Dropout2d.
+DROPOUT_MASKS = None
+_mask_at = [0]
+
+
+def set_dropout_masks(masks):
+    global DROPOUT_MASKS
+    DROPOUT_MASKS = list(masks) if masks else None
+    _mask_at[0] = 0
+
+
+class Drop2d(nn.Dropout2d):
+    """nn.Dropout2d (no parameters, no buffers: the state_dict does not see the difference) with the mask injectable"""
+
+    def forward(self, x):
+        if DROPOUT_MASKS is None or not self.training or self.p == 0:
+            return super().forward(x)
+        m = DROPOUT_MASKS[_mask_at[0] % len(DROPOUT_MASKS)]
+        _mask_at[0] += 1
+        return x * (m.to(x.dtype) / (1.0 - self.p))[:, :, None, None]
+
+
 class conv_block(nn.Module):
-    def __init__(self, ch_in, ch_out):
+    def __init__(self, ch_in, ch_out, act=nn.ReLU, drop_rate=0.0):
         super().__init__()
         self.init_conv = nn.Conv2d(ch_in, ch_out, 3, 1, 1)
-        self.conv = nn.Sequential(nn.Conv2d(ch_out, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), nn.Dropout2d(0.0),
-                                  nn.ReLU(), nn.Conv2d(ch_out, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), nn.Dropout2d(0.0))
-        self.activation = nn.ReLU()
+        self.conv = nn.Sequential(nn.Conv2d(ch_out, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), Drop2d(drop_rate),
+                                  act(), nn.Conv2d(ch_out, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), Drop2d(drop_rate))
+        self.activation = act()
 
     def forward(self, x):
         i = self.init_conv(x)
@@ -61,10 +84,10 @@ class conv_block(nn.Module):
 
 
 class up_conv(nn.Module):
-    def __init__(self, ch_in, ch_out, scale_factor=2):
+    def __init__(self, ch_in, ch_out, act=nn.ReLU, drop_rate=0.0, scale_factor=2):
         super().__init__()
         self.up = nn.Sequential(nn.Upsample(scale_factor=scale_factor, mode="bilinear", align_corners=True),
-                                nn.Conv2d(ch_in, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), nn.Dropout2d(0.0), nn.ReLU())
+                                nn.Conv2d(ch_in, ch_out, 3, 1, 1), nn.BatchNorm2d(ch_out), Drop2d(drop_rate), act())
 
     def forward(self, x):
         return self.up(x)

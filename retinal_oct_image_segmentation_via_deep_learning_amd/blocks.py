@@ -40,10 +40,9 @@ class HipModule(nn.Module):
         return ops.to_nchw(a, self.compute_dtype)
 
 
-def _check_dropout(mod: nn.Module):
-    for m in mod.modules():
-        if isinstance(m, nn.Dropout2d) and m.p > 0 and m.training:
-            raise NotImplementedError("Dropout2d with p > 0 in training mode is not on the HIP path (reference default 0.0)")
+def _drops(mod: nn.Module) -> bool:
+    """True when a Dropout2d of the block is active (p > 0, training): the block then runs its general schedule."""
+    return any(isinstance(m, nn.Dropout2d) and m.p > 0 and m.training for m in mod.modules())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -151,9 +150,18 @@ def init_weights(net, init_type="normal"):
 # ------------------------------------------------------------------------------------------------
 # SD_Layer_Net/common.py
 # ------------------------------------------------------------------------------------------------
-def _relu_only(act):
-    if act is not nn.ReLU:
-        raise NotImplementedError("only act=nn.ReLU (the reference default) is on the HIP path")
+# act != nn.ReLU / Dropout2d(p > 0) (common.py:7,13,17,29,34): the GENERAL schedule -- convolutions and BatchNorm on the HIP
+# kernels with nothing deferred, Dropout2d (ops.dropout2d) and the activation module the constructor made (`act()`, as the
+# reference does) applied to the materialised NHWC tensor.  The activation must therefore be elementwise; the ones that look
+# at a dimension are refused.  nn.ReLU without dropout keeps the fused / deferred schedule.
+_DIM_ACTS = (nn.Softmax, nn.Softmax2d, nn.LogSoftmax, nn.Softmin, nn.GLU, nn.Threshold, nn.MultiheadAttention)
+
+
+def _check_act(act):
+    if not (isinstance(act, type) and issubclass(act, nn.Module)):
+        raise TypeError("act must be an nn.Module class constructed without arguments (the reference calls act())")
+    if issubclass(act, _DIM_ACTS):
+        raise NotImplementedError(f"act={act.__name__} is not elementwise: not on the HIP path")
 
 
 class conv_block(HipModule):
@@ -162,7 +170,8 @@ class conv_block(HipModule):
     def __init__(self, ch_in, ch_out, act=nn.ReLU, drop_rate=0.0, kernel_size=3, compute_dtype="bf16"):
         super().__init__()
         self.compute_dtype = compute_dtype
-        _relu_only(act)
+        _check_act(act)
+        self._relu = act is nn.ReLU
         if kernel_size != 3:
             raise NotImplementedError("only kernel_size=3 (the reference default) is on the HIP path")
         self.init_conv = nn.Conv2d(ch_in, ch_out, kernel_size=3, stride=1, padding=1, bias=True)
@@ -175,8 +184,13 @@ class conv_block(HipModule):
 
     def nhwc(self, a, a1=None):
         """a / a1: NHWC tensors or ops.LazyAct (BN + ReLU of the producer applied on load)."""
-        _check_dropout(self)
         dt = self.compute_dtype
+        if not self._relu or _drops(self):   # general schedule (see _check_act)
+            i = ops.conv_bn_act(dt, a, self.init_conv, x1=a1)
+            t = ops.conv_bn_act(dt, i, self.conv[0], self.conv[1])
+            t = self.conv[3](ops.dropout2d(t, self.conv[2].p, self.conv[2].training))
+            u = ops.conv_bn_act(dt, t, self.conv[4], self.conv[5])
+            return self.activation(ops.dropout2d(u, self.conv[6].p, self.conv[6].training) + i)
         # init_conv's bias add is deferred too: the next convolution and the residual sum apply it (OCT_XF_AFFINE)
         i = ops.conv_bn_act(dt, a, self.init_conv, x1=a1, lazy=True)
         # relu(bn(conv0(i))) has one consumer, a convolution: it is never written (deferred activation)
@@ -193,7 +207,8 @@ class up_conv(HipModule):
     def __init__(self, ch_in, ch_out, act=nn.ReLU, drop_rate=0.0, scale_factor=2, compute_dtype="bf16"):
         super().__init__()
         self.compute_dtype = compute_dtype
-        _relu_only(act)
+        _check_act(act)
+        self._relu = act is nn.ReLU
         if int(scale_factor) != scale_factor or scale_factor < 1:
             raise NotImplementedError("only integer scale factors are on the HIP path")
         self._factor = int(scale_factor)
@@ -205,8 +220,10 @@ class up_conv(HipModule):
     def nhwc(self, a, lazy=False):
         """lazy=True: the caller feeds the result to convolutions only (U_Net / AttU_Net: the gate's W_g and the
         concatenating conv_block) and gets an ops.LazyAct."""
-        _check_dropout(self)
         dt = self.compute_dtype
+        if not self._relu or _drops(self):   # general schedule (see _check_act): a materialised tensor, also for lazy=True
+            t = ops.conv_bn_act(dt, ops.BilinearUp.apply(dt, self._factor, a), self.up[1], self.up[2])
+            return self.up[4](ops.dropout2d(t, self.up[3].p, self.up[3].training))
         return ops.conv_bn_act(dt, ops.BilinearUp.apply(dt, self._factor, a), self.up[1], self.up[2], L.ACT_RELU, lazy=lazy)
 
     def forward(self, x):

@@ -663,6 +663,27 @@ def conv_bn_act(dtype, x0, conv, bn=None, act=L.ACT_NONE, x1=None, res=None, pre
     return r
 
 
+# Dropout2d (SD_Layer_Net/common.py:13,17,34: between BatchNorm and the activation): a keep flag per (image, channel), scaled
+# by 1 / (1 - p).  DROPOUT_MASK_HOOK[0] (tests): callable(n, c, p) -> [n, c] tensor of 0 / 1 keep flags, asked once per
+# Dropout2d application in forward order; None draws from torch's generator of the tensor's device.
+DROPOUT_MASK_HOOK = [None]
+
+
+def dropout2d(a, p: float, training: bool):
+    """a: materialised NHWC tensor.  Identity in eval mode and for p = 0 (the reference default)."""
+    if not training or p <= 0.0:
+        return a
+    n, c = a.shape[0], a.shape[-1]
+    if p >= 1.0:
+        return a * 0.0
+    hook = DROPOUT_MASK_HOOK[0]
+    keep = hook(n, c, p) if hook is not None else torch.bernoulli(torch.full((n, c), 1.0 - p, device=a.device))
+    keep = keep.to(device=a.device, dtype=torch.float32)
+    if tuple(keep.shape) != (n, c):
+        raise RuntimeError(f"dropout mask must be [{n}, {c}], got {tuple(keep.shape)}")
+    return a * (keep / (1.0 - p)).to(a.dtype).view(n, 1, 1, c)
+
+
 def materialise(dtype, a):
     """LazyAct -> the activated NHWC tensor (for a consumer that is not a convolution); tensors pass through."""
     if not isinstance(a, LazyAct):

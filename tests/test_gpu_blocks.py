@@ -21,6 +21,22 @@ class Dropins:
     from retinal_oct_image_segmentation_via_deep_learning_amd.SOTAS.Layers_Segment.SD_Layer_Net.common import (  # noqa: E402
         Attention_block, conv_block, up_conv)
 
+    @staticmethod
+    def set_dropout_masks(masks):
+        """ops.DROPOUT_MASK_HOOK: the fixture's keep masks in forward order (rewound by every call of this function)"""
+        from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+        if not masks:
+            ops.DROPOUT_MASK_HOOK[0] = None
+            return
+        at = [0]
+
+        def hook(n, c, p):
+            m = masks[at[0] % len(masks)]
+            at[0] += 1
+            assert tuple(m.shape) == (n, c)
+            return m
+        ops.DROPOUT_MASK_HOOK[0] = hook
+
 
 def close(got, ref, key, rel, floor=1e-4):
     ref = np.asarray(ref, np.float64)

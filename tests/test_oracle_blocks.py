@@ -20,6 +20,11 @@ BLOCKS = {
     "blk_conv_block": lambda m: m.conv_block(3, 8),
     "blk_up_conv": lambda m: m.up_conv(8, 4),
     "blk_attention": lambda m: m.Attention_block(8, 8, 4),
+    # act != nn.ReLU and Dropout2d(p > 0) under the keep masks the fixture recorded (common.py:7,13,17,29,34)
+    "blk_conv_block_drop": lambda m: m.conv_block(3, 8, drop_rate=0.2),
+    "blk_up_conv_drop": lambda m: m.up_conv(8, 4, drop_rate=0.2),
+    "blk_conv_block_leaky": lambda m: m.conv_block(3, 8, act=torch.nn.LeakyReLU),
+    "blk_up_conv_tanh_drop": lambda m: m.up_conv(8, 4, act=torch.nn.Tanh, drop_rate=0.2),
 }
 
 
@@ -28,6 +33,8 @@ def load_block(golden_dir, name, module, **kw):
     m = BLOCKS[name](module)
     m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}, strict=True)
     xs = [torch.from_numpy(z[f"x{i}"]) for i in range(2) if f"x{i}" in z.files]
+    # Dropout2d fixtures: the module family replays the recorded keep masks, one per Dropout2d application in forward order
+    module.set_dropout_masks([torch.from_numpy(z[k]) for k in sorted(k for k in z.files if k.startswith("mask"))])
     return z, m.train(), xs
 
 
@@ -109,8 +116,11 @@ def test_dropin_state_dicts_and_ctor_rules(golden_dir):
     assert "F_g" in str(api["attunet_ctor_msg"])        # the reference's ctor bug the drop-in papers over
     Cm.Attention_block(channels_g=8, channels_x=8, F_int=4)
     Cm.Attention_block(F_g=8, F_l=8, F_int=4)
+    Cm.conv_block(3, 8, act=torch.nn.LeakyReLU, drop_rate=0.3)      # elementwise activations and Dropout2d: the general schedule
     with pytest.raises(NotImplementedError):
-        Cm.conv_block(3, 8, act=torch.nn.LeakyReLU)
+        Cm.conv_block(3, 8, act=torch.nn.Softmax2d)                  # looks at a dimension: refused
+    with pytest.raises(TypeError):
+        Cm.up_conv(8, 4, act=torch.relu)                             # the reference calls act(): a module class
     with pytest.raises(L_error()):
         M.UnetConv(1, 4)(torch.zeros(1, 1, 8, 8))        # CPU tensor: no fallback
 

@@ -46,12 +46,40 @@ ref_sd.Attention_block = _att_both_spellings
 
 STRIDE, FULL = 211, 4096
 
+# Dropout2d(p > 0) under a FIXED mask: while a *_drop case runs, torch.nn.functional.dropout2d (what the reference's
+# nn.Dropout2d modules call) is replaced by a function that applies the keep flags recorded in the fixture, in call order.
+_MASKS = {"list": None, "i": 0}
+_real_dropout2d = F.dropout2d
+
+
+def _fixed_dropout2d(input, p=0.5, training=True, inplace=False):
+    if _MASKS["list"] is None or not training or p == 0:
+        return _real_dropout2d(input, p, training, inplace)
+    m = _MASKS["list"][_MASKS["i"] % len(_MASKS["list"])]
+    _MASKS["i"] += 1
+    return input * (m.to(input.dtype) / (1.0 - p))[:, :, None, None]
+
+
+def _rewind():
+    _MASKS["i"] = 0
+
+
+ACTS = (nn.ReLU, nn.LeakyReLU)   # activations whose kink at 0 the margin search keeps inputs away from
+
+
+def _min_nonzero(t):
+    """smallest non-zero magnitude (a channel dropped by Dropout2d reaches its activation as exact zeros: no rounding there)"""
+    a = t.abs()
+    a = a[a > 0]
+    return float(a.min()) if a.numel() else 1e9
+
 
 def relu_margin(m, *inputs):
     """smallest |pre-activation| over every ReLU of the module (a sign flip there is fp32 noise)"""
     zmin = [1e9]
-    hooks = [mod.register_forward_pre_hook(lambda _m, i: zmin.__setitem__(0, min(zmin[0], float(i[0].abs().min()))))
-             for mod in m.modules() if isinstance(mod, nn.ReLU)]
+    hooks = [mod.register_forward_pre_hook(lambda _m, i: zmin.__setitem__(0, min(zmin[0], _min_nonzero(i[0]))))
+             for mod in m.modules() if isinstance(mod, ACTS)]
+    _rewind()
     with torch.no_grad():
         m(*inputs)
     for h in hooks:
@@ -59,8 +87,21 @@ def relu_margin(m, *inputs):
     return zmin[0]
 
 
-def block_case(name, make, in_shapes, seed, init=None, thresh=2e-5):
-    """make() -> module; inputs N(0,1); cotangent r ~ N(0,1); loss = sum(out * r)."""
+def block_case(name, make, in_shapes, seed, init=None, thresh=2e-5, masks=None):
+    """make() -> module; inputs N(0,1); cotangent r ~ N(0,1); loss = sum(out * r).
+    masks: [(n, c), ...] shapes of the Dropout2d keep masks of one forward, drawn from the case's seed with keep rate 0.75."""
+    if masks:
+        gm = torch.Generator().manual_seed(seed + 5000)
+        _MASKS["list"] = [(torch.rand(s, generator=gm) < 0.75).float() for s in masks]
+        F.dropout2d = _fixed_dropout2d
+    try:
+        _block_case(name, make, in_shapes, seed, init, thresh)
+    finally:
+        F.dropout2d = _real_dropout2d
+        _MASKS["list"] = None
+
+
+def _block_case(name, make, in_shapes, seed, init, thresh):
     while True:
         torch.manual_seed(seed)
         m = make().train()
@@ -81,10 +122,15 @@ def block_case(name, make, in_shapes, seed, init=None, thresh=2e-5):
     m.load_state_dict(state0)          # the probe advanced the BN buffers
     md = m.double()
     xd = [x.double().requires_grad_(True) for x in xs]
+    _rewind()
     out = md(*xd)
     r = torch.randn(out.shape, generator=g)
     (out * r.double()).sum().backward()
     rec = {"seed": np.array(seed), "r": r.numpy(), "out": out.detach().numpy()}
+    if _MASKS["list"] is not None:
+        assert _MASKS["i"] == len(_MASKS["list"]), "one mask per Dropout2d application"
+        for j, mk in enumerate(_MASKS["list"]):
+            rec[f"mask{j}"] = mk.numpy()
     for i, x in enumerate(xs):
         rec[f"x{i}"] = x.numpy()
         rec[f"gx{i}"] = xd[i].grad.numpy()
@@ -173,8 +219,20 @@ def init_case():
     print("mgunet_init:", len(rec), "entries;", rec["bad_type_msg"])
 
 
+def widened_cases():
+    """act != nn.ReLU and Dropout2d(drop_rate > 0) of conv_block / up_conv (common.py:7,13,17,29,34)"""
+    block_case("blk_conv_block_drop", lambda: ref_common.conv_block(3, 8, drop_rate=0.2), [(3, 3, 16, 24)], 600,
+               masks=[(3, 8), (3, 8)])
+    block_case("blk_up_conv_drop", lambda: ref_common.up_conv(8, 4, drop_rate=0.2), [(3, 8, 8, 12)], 610, masks=[(3, 4)])
+    block_case("blk_conv_block_leaky", lambda: ref_common.conv_block(3, 8, act=nn.LeakyReLU), [(2, 3, 16, 24)], 620)
+    block_case("blk_up_conv_tanh_drop", lambda: ref_common.up_conv(8, 4, act=nn.Tanh, drop_rate=0.2), [(2, 8, 8, 12)], 630,
+               masks=[(2, 4)])
+
+
 def main():
     torch.set_num_threads(8)
+    if "--widened" in sys.argv:      # only the cases added in round 3 (the other fixtures stay byte-identical)
+        return widened_cases()
     block_case("blk_unetconv_bn", lambda: ref_mg.UnetConv(3, 8, True), [(2, 3, 16, 24)], 300)
     block_case("blk_unetconv_nobn", lambda: ref_mg.UnetConv(1, 8, False), [(2, 1, 16, 24)], 310)
     block_case("blk_unetup_deconv", lambda: ref_mg.UnetUp(16, 8, True), [(2, 16, 8, 12), (2, 8, 16, 24)], 320)
@@ -184,6 +242,7 @@ def main():
     block_case("blk_conv_block", lambda: ref_common.conv_block(3, 8), [(2, 3, 16, 24)], 360)
     block_case("blk_up_conv", lambda: ref_common.up_conv(8, 4), [(2, 8, 8, 12)], 370)
     block_case("blk_attention", lambda: ref_common.Attention_block(8, 8, 4), [(2, 8, 16, 24), (2, 8, 16, 24)], 380)
+    widened_cases()
     init_case()
     net_case("attunet_c3_2x32x48", lambda ci, nc: ref_sd.AttU_Net(ci, nc, channels=[4, 8, 16, 32, 64]), 400,
              2, 1, 3, 32, 48, thresh=1e-5, full_weights=True)
