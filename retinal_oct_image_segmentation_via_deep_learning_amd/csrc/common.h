@@ -26,6 +26,8 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
 int oct_conv_v2_stat_rows(const OctConvDesc* d);
 // gemm1.hip: transposed-convolution forward / data gradient as an eight-wave GEMM (1 taken / 0 not eligible / <0 error)
 int oct_conv_forward_g1(const OctConvDesc* d, const OctConvArgs* a, void* stream);
+int oct_conv_forward_roll3d(const OctConvDesc* d, const OctConvArgs* a, void* stream);   // roll3d.hip: 1 taken, 0 not eligible, < 0 error
+int oct_conv_roll3d_stat_rows(const OctConvDesc* d);                                        // BatchNorm partial rows it writes, or -1
 // igemm.hip: (kh, kw) of a descriptor (0, 0 -> from taps); false for unsupported sizes
 bool oct_conv_kernel_size(int taps, int kh_in, int kw_in, int* kh, int* kw);
 int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, int* query = nullptr);

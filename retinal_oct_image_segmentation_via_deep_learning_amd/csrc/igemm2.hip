@@ -1268,6 +1268,8 @@ static V2Plan plan_v2(const OctConvDesc* d) {
 }
 
 int oct_conv_v2_stat_rows(const OctConvDesc* d) {
+  const int roll = oct_conv_roll3d_stat_rows(d);   // first-level volumetric layers: the depth-rolling kernel (roll3d.hip)
+  if (roll >= 0) return roll;
   const V2Plan pl = plan_v2(d);
   return pl.ok ? pl.stat_rows : -1;
 }
@@ -1367,6 +1369,10 @@ static void launch_v2_dma(const Igemm2Params& p, int grid, hipStream_t s) {
 
 // returns 1 when the launch was taken by this path, 0 when the shape is not eligible, <0 on error
 int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream) {
+  if (d->depth > 0) {   // 3x3x3 with 32 input channels per depth tap: the depth-rolling walk (roll3d.hip)
+    const int rc = oct_conv_forward_roll3d(d, a, stream);
+    if (rc != 0) return rc;
+  }
   const V2Plan pl = plan_v2(d);
   if (!pl.ok) return 0;
   if (d->taps == 1) {   // transposed convolutions with N % 256 == 0: the eight-wave GEMM kernel (gemm1.hip)

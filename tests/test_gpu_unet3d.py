@@ -99,6 +99,57 @@ def test_conv3d_fprop_dgrad_wgrad_exact(env, dt, shape):
         assert torch.equal(slab1, slab), "Conv3d(1 -> F) wgrad, all depth taps in one launch"
 
 
+# depth-rolling kernel (roll3d.hip: Cin = 32 per depth tap, Cout = 32 / 64, whole 8 x 32 tiles): (volumes, depth, H, W, Cout, split,
+# transform on load).  320 columns for 256 workgroups (several columns per workgroup, ring slots running on across columns),
+# the shortest volume (depth 2: every item touches a padding slice), a 64-channel output split over two tensors (the data
+# gradient of a concat), BN + ReLU and plain-affine transforms on load (padding applies to the ACTIVATED tensor)
+ROLL = [(5, 3, 128, 128, 32, 0, "relu"), (2, 2, 8, 32, 32, 0, None), (1, 7, 24, 64, 64, 32, "affine"), (1, 5, 16, 32, 64, 0, "relu"),
+        (3, 4, 8, 96, 32, 0, None)]
+
+
+@pytest.mark.parametrize("shape", ROLL)
+def test_conv3d_depth_rolling_kernel_bit_exact(env, shape):
+    """3x3x3 convolution of 32 channels on the depth-rolling kernel against torch's float64 conv3d on exactly representable
+    operands: output, BatchNorm sums, and the same launch with OCT_ROLL3D-ineligible routing (igemm2's depth-tap mode) as a
+    second witness.  No reference counterpart (parity unpinned by the reference)."""
+    L, E = env
+    b, d, h, w, cout, split, xf = shape
+    g = torch.Generator().manual_seed(abs(hash(shape)) % 2**31 + 5)
+    eng = E.UNetEngine(1, 2, 4, "bf16")
+    x = ints(g, (b, 32, d, h, w))
+    bn = None
+    eff = x
+    if xf:
+        sc = torch.tensor([-1.0, -0.5, 0.5, 1.0, 2.0])[torch.randint(0, 5, (32,), generator=g)]
+        sh = torch.randint(-2, 3, (32,), generator=g) * 0.5
+        eff = x * sc.double().view(1, 32, 1, 1, 1) + sh.double().view(1, 32, 1, 1, 1)
+        if xf == "relu":
+            eff = eff.clamp_min(0)
+        bn = E.BNState(sc.float().cuda(), sh.float().cuda(), relu=(xf == "relu"))
+    wt = pow2(g, (cout, 32, 3, 3, 3))
+    src = E.Src(ndhwc(x, "bf16"), 32, bn)
+    n = b * d
+    from retinal_oct_image_segmentation_via_deep_learning_amd import _lib
+    import ctypes as C
+    ref = F.conv3d(eff, wt, padding=1)
+    assert ref.abs().max() * 8 < 2 ** 22
+    rnd = lambda t: t.float().to(torch.bfloat16).double()
+    c_a = split if split else cout
+    y0 = torch.full((n, h, w, c_a), float("nan"), dtype=torch.bfloat16, device="cuda")
+    y1 = torch.full((n, h, w, cout - split), float("nan"), dtype=torch.bfloat16, device="cuda") if split else None
+    rows = eng._stat_blocks(cout, n, h, w, src, depth=d)
+    assert rows == min(256, (w // 32) * (h // 8) * b), "the rolling kernel writes one BatchNorm row per workgroup"
+    part = torch.full((rows, 2, cout), float("nan"), dtype=torch.float32, device="cuda")
+    wp = eng._pack("w3", wt.float().cuda().contiguous(), L.PACK_CONV3D_FPROP, cout, 32)
+    eng._conv(src, wp, cout, 9, n, h, w, y0, y1=y1, split=split, stats=None if split else part, depth=d)
+    got = from_ndhwc(y0, b) if not split else torch.cat([from_ndhwc(y0, b), from_ndhwc(y1, b)], dim=1)
+    assert torch.equal(got, rnd(ref)), "depth-rolling Conv3d"
+    if not split:
+        assert torch.equal(part.double().sum(0)[0].cpu(), ref.sum(dim=(0, 2, 3, 4))), "BatchNorm3d sum(y)"
+        # (the squares leave the exactly representable range of the fp32 partial sums: a tolerance, as in test_gpu_exact.py)
+        torch.testing.assert_close(part.double().sum(0)[1].cpu(), (ref * ref).sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-2)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 2, 4, 8, 16, 8), (1, 3, 8, 32, 64, 32)])
 def test_deconv3d_fwd_dgrad_wgrad_exact(env, dt, shape):
