@@ -180,18 +180,31 @@ __global__ void __launch_bounds__(512) roll3d_kernel(const RollParams p) {
   // addressed as a wave-uniform 64-bit base (SGPRs) + compile-time byte offset + one 32-bit lane offset: `global_load_dwordx4 v,
   // v_off, s[base]`.  (With a per-lane pointer hipcc hoists the 54 fragment addresses of the unrolled item out of the stage
   // loop -- 108 VGPRs of loop-invariant pointers, 80-316 bytes of scratch; the base is therefore re-laundered every stage.)
-  const unsigned char* wu = reinterpret_cast<const unsigned char*>(p.wp + ((size_t)wn * 9 * 6) * 512);
+  // (an explicit GLOBAL pointer: after the laundering hipcc no longer knows where a generic pointer points, emits flat_load and
+  //  then waits with vmcnt(0) lgkmcnt(0) at every use -- six drains of the ring and of all earlier stores per item)
+  typedef const __attribute__((address_space(1))) unsigned char* gbytes;
+  typedef const __attribute__((address_space(1))) Frag* gfrag;
+  gbytes wu = (gbytes)reinterpret_cast<const unsigned char*>(p.wp + ((size_t)wn * 9 * 6) * 512);
   const unsigned wlane = (unsigned)lane * 16u;
+  auto wload = [&](int off) -> Frag { return *(gfrag)(wu + off + wlane); };
   auto woff = [](int s) constexpr { const int kd = s / 18, t = (s % 18) >> 1, k16 = s & 1; return (t * 6 + kd * 2 + k16) * 1024; };
 #pragma unroll
-  for (int j = 0; j < PF; ++j) wring[j] = M::load(wu + woff(j) + wlane);
+  for (int j = 0; j < PF; ++j) wring[j] = wload(woff(j));
 
   // deferred epilogue (igemm2.hip): the item's fragments are only packed to bf16; the LDS transpose and the stores ride
   // between the MFMA steps of the next item
   constexpr int NFR = MF;
   constexpr int ESTRIDE = (KSTEPS - 2) / NFR;
+  // The deferred stores are UNCONDITIONAL: a wave-uniform `if (pending)` around them made hipcc lose count of the outstanding
+  // memory operations and wait with s_waitcnt vmcnt(0) -- a drain of the weight ring and of every earlier store -- six times
+  // per item (4.5 ms per launch for 1.9 ms of matrix work).  So there is always a "previous item": before the first one it is
+  // the first item itself with zeros (same wave, same lanes, same addresses: the real values follow one stage later, in
+  // program order), and a column's last item simply waits through the two bubble stages of the next column.
   unsigned packed[MF][8];
-  bool pend = false;
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) packed[m][q] = 0u;
   unsigned char* e_fb = nullptr;
   unsigned e_rowb = 0, e_pstep = 0;
   auto set_item = [&](int img, int tyi, int txi) {
@@ -225,21 +238,17 @@ __global__ void __launch_bounds__(512) roll3d_kernel(const RollParams p) {
     }
   };
   auto flush = [&]() {
-    if (pend) {
 #pragma unroll
-      for (int idx = 0; idx < NFR; ++idx) store_frag(idx);
-      pend = false;
-    }
+    for (int idx = 0; idx < NFR; ++idx) store_frag(idx);
   };
 
   __syncthreads();   // stage 0 is in LDS
   int j = 0, col = blockIdx.x;
   int txi = col % p.tiles_x, tyi = (col / p.tiles_x) % p.tiles_y, vol = col / (p.tiles_x * p.tiles_y);
+  set_item(vol * p.depth, tyi, txi);
   for (int g = 0; g < nstage_pad; ++g) {
     if (g >= nstage) { __syncthreads(); continue; }
-    if (j < 2) {
-      flush();   // a column starts: nothing to multiply for two stages
-    } else {
+    if (j >= 2) {   // (j = 0, 1: a column starts, nothing to multiply yet)
       asm volatile("" : "+s"(wu));   // keeps the fragment addresses of this stage out of the loop preheader (see above)
       const int lane_off = ((wm * MF) * LW + r) * PIXB + 16 * hh;
       const unsigned char* lbk[3];
@@ -267,12 +276,9 @@ __global__ void __launch_bounds__(512) roll3d_kernel(const RollParams p) {
           if (s == 0) M::mma0(acc[m], wring[s % PF], xr[s % (LD + 1)][m]);
           else M::mma(acc[m], wring[s % PF], xr[s % (LD + 1)][m]);
         }
-        wring[s % PF] = M::load(wu + woff((s + PF) % KSTEPS) + wlane);   // the sequence repeats every item: the ring cycles
-        if (s >= 1 && (s - 1) % ESTRIDE == 0 && (s - 1) / ESTRIDE < NFR) {
-          if (pend) store_frag((s - 1) / ESTRIDE);
-        }
+        wring[s % PF] = wload(woff((s + PF) % KSTEPS));   // the sequence repeats every item: the ring cycles
+        if (s >= 1 && (s - 1) % ESTRIDE == 0 && (s - 1) / ESTRIDE < NFR) store_frag((s - 1) / ESTRIDE);   // previous item
       }
-      pend = false;   // ESTRIDE * NFR <= KSTEPS - 2: every fragment of the previous item went out above
       // ---- this item: pack, BatchNorm sums, hand the stores to the next stage ----
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
@@ -287,7 +293,6 @@ __global__ void __launch_bounds__(512) roll3d_kernel(const RollParams p) {
         }
       }
       set_item(vol * p.depth + (j - 2), tyi, txi);
-      pend = true;
     }
     __syncthreads();
     if (++j == spc) {
@@ -327,7 +332,15 @@ static bool roll_enabled() {
   return on == 1;
 }
 
+// Which launches: measured on cfg5 (profiles/r03_cfg5_kernel_table.txt, same box): 32 -> 32 forward with BatchNorm sums 4.9 -> 3.96 ms,
+// the 32 -> 64 data gradient 7.6 -> 6.6 ms, but the 32 -> 32 data gradient (no sums) 3.25 -> 3.97 ms -- igemm2's 16-row tile gives
+// each weight fragment four MFMAs, the 8-row tile the ring forces (four 16-row slice tiles do not fit the LDS) only two, and at
+// Cout = 32 all four MFMA waves stream the SAME 54 KB of filter per item: 62 B/clk per CU of L2 requests beside 128 B/clk of LDS
+// reads, both at the CU's limits.  Those stay on igemm2 (OCT_ROLL3D=2 forces every eligible launch here).
 static bool roll_ok(const OctConvDesc* d) {
+  static int all = -1;
+  if (all < 0) { const char* e = getenv("OCT_ROLL3D"); all = (e && e[0] == '2') ? 1 : 0; }
+  if (!all && d->cout == 32 && !d->want_stats) return false;
   return roll_enabled() && d->dtype == OCT_DT_BF16 && d->depth > 0 && d->taps == 9 && d->kh != 7 && d->in_mode == OCT_IN_PLAIN &&
          d->out_mode == OCT_OUT_PLAIN && d->c0 == 32 && d->c1 == 0 && (d->cout == 32 || d->cout == 64) &&
          (d->split == 0 || (d->cout == 64 && d->split == 32)) && (d->w % 32) == 0 && (d->h % 8) == 0 && (d->n % d->depth) == 0 &&

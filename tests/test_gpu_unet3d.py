@@ -139,6 +139,8 @@ def test_conv3d_depth_rolling_kernel_bit_exact(env, shape):
     y1 = torch.full((n, h, w, cout - split), float("nan"), dtype=torch.bfloat16, device="cuda") if split else None
     rows = eng._stat_blocks(cout, n, h, w, src, depth=d)
     assert rows == min(256, (w // 32) * (h // 8) * b), "the rolling kernel writes one BatchNorm row per workgroup"
+    # (a 32-channel output WITHOUT BatchNorm sums stays on igemm2's 16-row tiles, see roll3d.hip: every case here asks for
+    #  the sums or has 64 output channels)
     part = torch.full((rows, 2, cout), float("nan"), dtype=torch.float32, device="cuda")
     wp = eng._pack("w3", wt.float().cuda().contiguous(), L.PACK_CONV3D_FPROP, cout, 32)
     eng._conv(src, wp, cout, 9, n, h, w, y0, y1=y1, split=split, stats=None if split else part, depth=d)
