@@ -695,7 +695,29 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     frag_store(m, q, tv);
   };
 
+#ifndef IG2_EARLYB
+#define IG2_EARLYB 0   /* measured (r3, same box, two runs each): 11.36 / 11.36 ms without, 11.42 / 11.34 ms with, over the 3x3 launches */
+#endif
+  // EARLYB (16x16x32 kernels, off): the activation fragments of a stage's FIRST half-step are read right behind the barrier that
+  // publishes the stage, before the ~240 instructions of per-stage set-up (statistics flush, accumulator clear, weight
+  // addresses) that precede them in program order.  The idea: the first MFMA of a stage waits an LDS round trip behind that
+  // set-up.  The in-kernel timeline (profiles/r03_ig2_timeline_late.txt) shows the stage IS bound by the MFMA waves (they wait
+  // ~100 cycles at the barrier, the producers ~2.9 k), but moving the reads changed no launch: the set-up is long enough to
+  // cover the round trip either way.
+  constexpr bool EARLYB = IG2_EARLYB && M16 && !(IG2_WRING4 && MF == 4 && !RAGGED);
+  Frag b16e[EARLYB ? MF : 1];
+  auto early_b = [&](int cur_) {
+    if constexpr (EARLYB) {
+      const int r16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        if constexpr (DMA) b16e[m] = M::load(smem + (unsigned)(cur_ * BUFB + ((wm * MF + m) * LW + r16) * 64 + ((kg ^ ((r16 >> 1) & 3)) * 16)));
+        else b16e[m] = M::load(buf0 + cur_ * BUFB + ((wm * MF + m) * LW + r16) * PIXB + kg * 16);
+      }
+    }
+  };
   __syncthreads();  // stage 0 is in LDS
+  early_b(0);
   int cur = 0, pending_tile = -1, pending_nbi = 0, parity = 0;
   int item = 0, ch = 0;                                        // item = index within this workgroup's items
   int tile_c = t_first, nbi_c = nbi_first;                     // (tile, channel block) of `item`, kept as counters:
@@ -937,7 +959,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         } else {
         Frag b16[2][MF];
 #pragma unroll
-        for (int m = 0; m < MF; ++m) b16[0][m] = M::load(bptr(0, m));
+        for (int m = 0; m < MF; ++m) {
+          if constexpr (EARLYB) b16[0][m] = b16e[m];   // read right behind the barrier
+          else b16[0][m] = M::load(bptr(0, m));
+        }
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {   // half-step s = 2*tap + pixel half
           const int t = s >> 1;
@@ -1151,6 +1176,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
     if (p.trace && blockIdx.x == 0 && wave == 0 && lane == 0 && sidx == nstage - 1) p.trace[2044] = __builtin_amdgcn_s_memrealtime();
 #endif
     cur = DMA ? (cur + 1 == NBUF ? 0 : cur + 1) : (cur ^ 1);
+    early_b(cur);
     if (++ch == p.nch) {
       ch = 0; ++item;
       if (++nbi_c == p.nblk) {

@@ -41,10 +41,13 @@ stage = np.diff(t[3, :ns])
 f = lambda a: f"med {np.median(a):8.0f}  mean {np.mean(a):8.0f}  max {np.max(a):8.0f}"
 print("consumer: MFMA phase ", f(c_phase)); print("consumer: epilogue   ", f(c_epi)); print("consumer: barrier    ", f(c_bar))
 print("producer: commit     ", f(p_commit)); print("producer: issue      ", f(p_issue)); print("producer: barrier    ", f(p_bar))
+print("producer: busy (4->6)", f(t[6, :ns] - t[4, :ns]), " (commit + issue together: the interleaved loop stamps no slot 5)")
+print("consumer: top (3->0') ", f(t[0, 1:ns] - t[3, :ns - 1]), " (barrier release -> next MFMA phase start)")
 print("stage period         ", f(stage))
 print("first 10 stages: phase", c_phase[:10], "epi", c_epi[:10], "cbar", c_bar[:10], "commit", p_commit[:10], "pbar", p_bar[:10])
 if os.environ.get("TRACE_FULL"):
     np.set_printoptions(linewidth=250)
     k = min(ns, 24)
     print("phase ", c_phase[:k]); print("epi   ", c_epi[:k]); print("cbar  ", c_bar[:k]); print("commit", p_commit[:k]); print("issue ", p_issue[:k]); print("pbar  ", p_bar[:k]); print("period", stage[:k])
+    print("pbusy ", (t[6, :k] - t[4, :k])); print("ctop  ", (t[0, 1:k + 1] - t[3, :k]))
     print("producer start rel. consumer phase start:", (t[4, :k] - t[0, :k]))
