@@ -708,6 +708,9 @@ class UNetEngine:
             wp = self._pack(wkey, P[wkey], L.PACK_DECONV_DGRAD, cout_d, cin_d)
             da = self._act(n, hl, wl, cin_d, dev)
             self._conv(Src(du, cout_d), wp, cin_d, 1, n, hl, wl, da, in_mode=L.IN_S2D)
+            if self.debug is not None:   # teacher forcing of the transposed convolution (tests): what its three kernels read and wrote
+                self.debug["up:" + wkey] = dict(x=prev.y.float().clone(), bn=(prev.bn.scale.clone(), prev.bn.shift.clone()),
+                                                u=u.float().clone(), du=du.float().clone(), da=da.float().clone(), bkey=bkey)
             self._stage_done(stage_hook, nd - 1 - di)
         dpool, _ = self._block_backward(sp.enc[-1].name, da, None, G, accumulate)
         self._stage_done(stage_hook, nd)

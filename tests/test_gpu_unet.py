@@ -455,7 +455,7 @@ def test_disable_v2_switch_runs_the_headline_width_in_bf16():
 
 
 def test_headline_width_bf16_layers_teacher_forced_against_oracle(golden_dir):
-    """Every 3x3 layer of the benchmarked network, IN SITU: the bf16 step runs once on the reference-pinned wide
+    """Every 3x3 layer and every transposed convolution of the benchmarked network, IN SITU: the bf16 step runs once on the reference-pinned wide
     fixture, and each layer is then redone by the oracle from the tensors the kernels actually read (its own bf16
     inputs, BatchNorm coefficients and incoming dY).  Errors cannot compound this way, so the bound is the one a single
     bf16 store allows -- a free-running comparison cannot have it: with bf16 storage a 1-ulp difference in an early
@@ -504,6 +504,23 @@ def test_headline_width_bf16_layers_teacher_forced_against_oracle(golden_dir):
         u = ulps(dx, R.round_bf16(dx_ref))
         # (a heavily cancelling sum can sit several bf16 ulps of its own small value away from the fp32 accumulation)
         assert (u > 0).mean() < 1e-2 and (u > 1.01).mean() < 1e-4 and u.max() < 64, (wk, "dgrad", (u > 0).mean(), u.max())
+    # the four transposed convolutions, the same way: forward with BN + ReLU on load and the depth-to-space
+    # store (+ bias), data gradient through the space-to-depth gather, weight and bias gradient from the dU they received
+    ups = [k for k in dbg if k.startswith("up:")]
+    assert len(ups) == 4
+    for key in ups:
+        rec, wk = dbg[key], key[3:]
+        a = act(rec["x"], rec["bn"])
+        wq = R.round_bf16(state[wk])
+        u_ref = R.deconv2x2_fwd(a, wq, state[rec["bkey"]].astype(np.float64))
+        uu = ulps(nchw(rec["u"]), R.round_bf16(u_ref))
+        assert (uu > 0).mean() < 1e-2 and (uu > 1.01).mean() < 1e-4 and uu.max() < 64, (wk, "deconv fprop", (uu > 0).mean(), uu.max())
+        du = nchw(rec["du"])
+        da_ref, dw_ref, db_ref = R.deconv2x2_bwd(a, wq, du)
+        assert rel_l2(grads[wk], dw_ref) < 2e-3, (wk, "deconv wgrad", rel_l2(grads[wk], dw_ref))
+        assert rel_l2(grads[rec["bkey"]], db_ref) < 2e-3, (wk, "deconv bias gradient", rel_l2(grads[rec["bkey"]], db_ref))
+        uu = ulps(nchw(rec["da"]), R.round_bf16(da_ref))
+        assert (uu > 0).mean() < 1e-2 and (uu > 1.01).mean() < 1e-4 and uu.max() < 64, (wk, "deconv dgrad", (uu > 0).mean(), uu.max())
 
 
 @pytest.mark.parametrize("dtype,shape", [("bf16", (2, 128, 256)), ("f32", (2, 32, 64))])
