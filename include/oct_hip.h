@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCT_VERSION 210 /* 0.2.1: + oct_bilinear_resize_*, floor-mode max-pooling (MGU-Net); 0.2.0: (kh,kw) kernels, depth taps, partials, ReLayNet / 3-D / per-class metric entry points */
+#define OCT_VERSION 220 /* 0.2.2 (round 3): 7x3 on the pipelined kernels, oct_rowdot_* up to 12 outputs, frozen-BatchNorm backward, depth-rolling 3-D kernel; 0.2.1: + oct_bilinear_resize_*, floor-mode max-pooling (MGU-Net); 0.2.0: (kh,kw) kernels, depth taps, partials, ReLayNet / 3-D / per-class metric entry points */
 
 /* dtypes of activation storage */
 #define OCT_DT_BF16 0

@@ -39,6 +39,23 @@ int oct_first_wgrad(const OctWgradDesc* d, const OctWgradArgs* a, void* stream, 
 // lower clamp of the on-load transform a = max(x*scale + shift, floor): 0 for BN + ReLU (OCT_XF_AFFINE_RELU), -inf for the
 // plain per-channel affine (OCT_XF_AFFINE: a deferred bias add) -- the same v_max either way
 __device__ __forceinline__ float xf_floor(int xf) { return xf == 2 ? -__builtin_inff() : 0.f; }
+// The same clamp applied AFTER the pair has been rounded to bf16: one v_pk_max_i16 per pair instead of two v_max_f32 (the
+// producers' vector instructions come straight out of the co-resident MFMA wave's cycles: MI355X_MICROARCH.md, "Two waves per
+// SIMD").  A bf16 as a signed 16-bit integer is negative exactly when its sign bit is set, so max(x, 0) as integers is the ReLU
+// of the rounded value -- and rounding is monotonic with round(0) = 0, so relu(round(x)) == round(relu(x)) bit for bit; the
+// plain-affine clamp is the most negative integer (identity).  (NaN: a positive NaN stays NaN where fmaxf returned 0.)
+// Measured (r3, same box, two runs each): igemm2 3x3 launches 11.30 / 11.39 ms without, 11.31 / 11.33 ms with; wgrad2 5.88 / 5.86 ms
+// without, 6.01 / 6.04 ms WITH (+2.7 %): like the packed-f32 forms (MI355X_MICROARCH.md constants table) the packed 16-bit op costs
+// more beside MFMAs than the two scalar ops it replaces.  Off; bit-exact either way (tests/test_gpu_exact.py ran on both).
+#ifndef OCT_PK_RELU
+#define OCT_PK_RELU 0
+#endif
+__device__ __forceinline__ unsigned xf_floor_pk(int xf) { return xf == 2 ? 0x80008000u : 0u; }
+__device__ __forceinline__ unsigned pk_clamp_bf16(unsigned v, unsigned floor_pk) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), __builtin_bit_cast(s16x2, floor_pk));
+  return __builtin_bit_cast(unsigned, r);
+}
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);

@@ -154,10 +154,18 @@ __global__ void __launch_bounds__(1024) head_loss_finalize_kernel(const double* 
   {
     // 1024 threads: slot = tid % 64, sixteenth of the block range = tid / 64
     const int slot = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    double s = 0.0;
-    if (slot < OCT_HEAD_LOSS_SLOTS)
-      for (int b = seg; b < nblocks; b += 16) s += partials[(size_t)b * OCT_HEAD_LOSS_SLOTS + slot];
-    part[seg][slot] = s;
+    // eight independent partial sums per thread: the block range is walked with eight loads in flight instead of one
+    // dependent load per ~2 us round trip (the kernel was 56 us for 4096 rows: profiles/r03_bench_kernel_stats.csv)
+    double sv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (slot < OCT_HEAD_LOSS_SLOTS) {
+      int b = seg;
+      for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] += partials[(size_t)(b + 16 * u) * OCT_HEAD_LOSS_SLOTS + slot];
+      }
+      for (; b < nblocks; b += 16) sv[0] += partials[(size_t)b * OCT_HEAD_LOSS_SLOTS + slot];
+    }
+    part[seg][slot] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
     __syncthreads();
     if (threadIdx.x < OCT_HEAD_LOSS_SLOTS) {
       double a = 0.0;

@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) issue_slot(st, i, Rr[i], vm);
     };
-    struct CommitSt { float s[8], b[8]; float flo; bool xf; };
+    struct CommitSt { float s[8], b[8]; float flo; unsigned flo_pk; bool xf; };
     auto commit_begin = [&](bool always) -> CommitSt {
       CommitSt st;
       const int ch = c_ch;
@@ -397,6 +397,7 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       const bool first = s2d || chc * 32 < p.c0;
       st.xf = first ? (p.xf0 != 0) : (p.xf1 != 0);
       st.flo = xf_floor(first ? p.xf0 : p.xf1);   // wave-uniform: 0 (BN + ReLU) or -inf (plain affine)
+      st.flo_pk = xf_floor_pk(first ? p.xf0 : p.xf1);
       if (st.xf || always) {
         const int kx = s2d ? p.c0 : p.c0 + p.c1;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sxf + cg), s1 = *reinterpret_cast<const f32x4*>(sxf + cg + 4);
@@ -419,9 +420,13 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
         {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
+            if (OCT_PK_RELU) {
+              v[j] = pk_clamp_bf16(pack_bf16x2(fmaf(bf16lo(v[j]), st.s[2 * j], st.b[2 * j]), fmaf(bf16hi(v[j]), st.s[2 * j + 1], st.b[2 * j + 1])), st.flo_pk);
+            } else {
             const float lo = fmaxf(fmaf(bf16lo(v[j]), st.s[2 * j], st.b[2 * j]), st.flo);
             const float hi = fmaxf(fmaf(bf16hi(v[j]), st.s[2 * j + 1], st.b[2 * j + 1]), st.flo);
             v[j] = pack_bf16x2(lo, hi);
+            }
           }
         }
         // out-of-image pixels are exactly zero (padding applies to the activated tensor)

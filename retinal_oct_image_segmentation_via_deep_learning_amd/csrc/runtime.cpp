@@ -24,7 +24,7 @@ int oct_check_launch(const char* what) {
 }
 
 extern "C" {
-const char* oct_version_string(void) { return "oct_hip 0.2.1 (gfx950)"; }
+const char* oct_version_string(void) { return "oct_hip 0.2.2 (gfx950)"; }
 int oct_version(void) { return OCT_VERSION; }
 int oct_get_last_error(char* buf, size_t len) {
   if (!buf || len == 0) return OCT_E_INVALID;

@@ -158,6 +158,9 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
 
   if (wave >= 4) {
     // ============================== producer waves ==============================
+#ifdef W2_PROD_PRIO
+    __builtin_amdgcn_s_setprio(W2_PROD_PRIO);
+#endif
     const int ptid = tid - 256, g = ptid & 3, pb = ptid >> 2;
     constexpr int SIB = (NPI * 4 + 255) / 256;   // input slots per 32-channel block (256 producer threads)
     constexpr int SDB = (NPD * 4 + 255) / 256;   // dY slots per 32-row block
@@ -312,6 +315,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
         const bool second = cg >= p.c0;
         const bool xf = second ? (p.xf1 != 0) : (p.xf0 != 0);
         const float flo = xf_floor(second ? p.xf1 : p.xf0);   // wave-uniform: 0 (BN + ReLU) or -inf (plain affine)
+        const unsigned flo_pk = xf_floor_pk(second ? p.xf1 : p.xf0);
         float s[8], b[8];
         if (xf) {
           const float* sc = sxf + blk * 32 + g * 8;
@@ -328,9 +332,14 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
             if (xf) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
+                if (OCT_PK_RELU) {
+                  v[e] = pk_clamp_bf16(w2_pack(fmaf(__uint_as_float(v[e] << 16), s[2 * e], b[2 * e]),
+                                               fmaf(__uint_as_float(v[e] & 0xffff0000u), s[2 * e + 1], b[2 * e + 1])), flo_pk);
+                } else {
                 const float lo = fmaxf(fmaf(__uint_as_float(v[e] << 16), s[2 * e], b[2 * e]), flo);
                 const float hi = fmaxf(fmaf(__uint_as_float(v[e] & 0xffff0000u), s[2 * e + 1], b[2 * e + 1]), flo);
                 v[e] = w2_pack(lo, hi);
+                }
               }
             }
             const bool live = ((S.vm[blk] >> j) & 1u) != 0;
@@ -383,7 +392,10 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   }
 
   // ================================ MFMA waves ================================
-  __builtin_amdgcn_s_setprio(3);  // win issue arbitration against the co-resident producer wave
+#ifndef W2_MFMA_PRIO
+#define W2_MFMA_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(W2_MFMA_PRIO);  // win issue arbitration against the co-resident producer wave
   const int pair = MULTI ? 0 : wave % PAIRS, psx = MULTI ? 0 : wave / PAIRS;
   const int cb = MULTI ? (wave >> 1) * WCB : pair / IB, ib = MULTI ? (wave & 1) * WIB : pair % IB;   // MULTI: first pair of the wave's sub-block
   const int g4 = lane >> 4, li = lane & 15;
