@@ -1432,10 +1432,9 @@ int oct_conv_forward_v2(const OctConvDesc* d, const OctConvArgs* a, void* stream
   hipStream_t s = as_stream(stream);
   const bool dma = dma_enabled() && !d->xform0 && !d->xform1 && d->c1 == 0 && !d->want_stats && !pl.wres && pl.th == 8 &&
                    d->depth == 0 && d->out_img_mul == 0 && (d->w % 32) == 0 && (d->h % 8) == 0 && pl.nt >= 64 &&
-                   ((d->taps != 1) || (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN));
+                   ((d->taps == 9) || (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN));   // (7x3: the LDS-DMA variant spills 8 dwords and measured 1 % slower on ReLayNet's data gradients)
   if (dma) {
     if (d->taps == 9) { if (pl.nt == 64) launch_v2_dma<9, 2, 2, 4, 1>(p, pl.grid, s); else launch_v2_dma<9, 2, 2, 4, 2>(p, pl.grid, s); }
-    else if (d->taps == 21) { if (pl.nt == 64) launch_v2_dma<21, 2, 2, 4, 1>(p, pl.grid, s); else launch_v2_dma<21, 2, 2, 4, 2>(p, pl.grid, s); }
     else { if (pl.nt == 64) launch_v2_dma<1, 2, 2, 4, 1>(p, pl.grid, s); else launch_v2_dma<1, 2, 2, 4, 2>(p, pl.grid, s); }
   } else if (d->taps == 21) {
     if (pl.nt == 64) launch_v2<2, 2, 4, 1, false, 21>(p, pl.grid, s); else launch_v2<2, 2, 4, 2, false, 21>(p, pl.grid, s);

@@ -307,7 +307,8 @@ def test_conv3x3_wgrad_with_fused_bias_gradient_bit_exact(env, shape):
 # launches), the others on the generic ones: several tile rows (interior tiles), ragged heights with 4 and 6 rows left,
 # ragged widths, concat sources, whole tiles (LDS-DMA data gradient), and a height the pipelined kernels refuse (9 = 8 + 1)
 KK73 = [(2, 16, 32, 32, 0, 32), (1, 14, 40, 64, 0, 64), (1, 16, 32, 64, 64, 64), (2, 9, 24, 32, 0, 96),
-        (1, 40, 64, 64, 0, 64), (1, 30, 64, 64, 64, 64), (2, 24, 64, 128, 0, 128), (1, 20, 40, 64, 0, 64), (1, 17, 32, 64, 0, 64)]
+        (1, 40, 64, 64, 0, 64), (1, 30, 64, 64, 64, 64), (2, 24, 64, 128, 0, 128), (1, 20, 40, 64, 0, 64), (1, 17, 32, 64, 0, 64),
+        (1, 5, 32, 96, 32, 192), (1, 3, 64, 64, 0, 64), (2, 11, 32, 64, 0, 128)]   # three channel blocks / chunks, images lower than the kernel, 3 rows left
 
 
 @pytest.mark.parametrize("shape", KK73)
