@@ -536,7 +536,10 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
 #ifndef IG2_PF4
 #define IG2_PF4 9
 #endif
-  constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? 3 : ((MF * NF >= 4) ? (TAPS == 21 ? 7 : IG2_PF4) : 9));   // PF4: 6 until round 3 (42 steps: 7)
+#ifndef IG2_PF8
+#define IG2_PF8 3
+#endif
+  constexpr int PF = (KSTEPS == 2) ? 2 : ((MF * NF >= 8) ? ((KSTEPS % IG2_PF8 == 0) ? IG2_PF8 : 3) : ((MF * NF >= 4) ? (TAPS == 21 ? 7 : IG2_PF4) : 9));   // PF4: 6 until round 3 (42 steps: 7)
   static_assert(KSTEPS % PF == 0, "ring slots must line up across stages");
   Frag wring[(WRES || M16) ? 1 : PF][NF];
   // M16: weights of two taps.  Tap t sits in slot t & 1 and tap t + 1 is fetched while it multiplies; a stage has nine taps,
