@@ -1075,8 +1075,114 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
       // Not deferred (two channel fragments per wave): fragment f's bf16 pairs go to LDS scratch slot f & 1 while fragment
       // f - 1 is read back from the other slot and stored, and the BatchNorm sums of f fill the LDS round trip -- back to
       // back (write, wait, read, wait, store per fragment) the eight fragments took 6.3 k cycles per item (timeline, round 2).
+      auto stats_to_ws = [&](int q) {   // the BatchNorm sums of channel fragment q of this item: registers -> wg_stats[parity]
+        float* ws = wg_stats + parity * (WM * 2 * NT);
+        {
+          if constexpr (M16) {
+            // registers 4*(2*half + cc) + e: both pixel halves carry the same channels 16*cc + 4*(lane>>4) + e
+            float v1[8], v2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v1[k] = s1[q][k] + s1[q][8 + k]; v2[k] = s2[q][k] + s2[q][8 + k]; }
+            const float t1 = reduce16_scatter8(v1, lane);
+            const float t2 = reduce16_scatter8(v2, lane);
+            if ((lane & 1) == 0) {
+              const int reg = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+              const int cl = (wn * NF + q) * 32 + 16 * (reg >> 2) + 4 * (lane >> 4) + (reg & 3);
+              ws[(wm * 2 + 0) * NT + cl] = t1;
+              ws[(wm * 2 + 1) * NT + cl] = t2;
+            }
+          } else {
+          const float t1 = reduce32_scatter16(s1[q], lane);
+          const float t2 = reduce32_scatter16(s2[q], lane);
+          if ((lane & 1) == 0) {
+            const int reg = scatter16_reg_of_lane(lane);
+            const int cl = (wn * NF + q) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            ws[(wm * 2 + 0) * NT + cl] = t1;
+            ws[(wm * 2 + 1) * NT + cl] = t2;
+          }
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { s1[q][i] = 0.f; s2[q][i] = 0.f; }
+        }
+      };
+#ifndef IG2_MRG
+#define IG2_MRG 1
+#endif
+      // MRG (two channel fragments per wave, 16x16x32): the wave's 64 channels of a pixel are 128 contiguous bytes -- one cache
+      // line -- but stored fragment by fragment every store instruction wrote sixteen HALF lines (16 pixels x 64 B).  What a
+      // store costs the CU is per line touched, not per byte (a timing build without the stores ran the 3x3 launches 15 % faster,
+      // 17-27 % on the data gradients; halving the MFMA waves' store COUNT by handing fragments to other waves changed nothing):
+      // both fragments of an output row go through one [32 px][128 B] scratch tile and leave as four instructions of eight FULL
+      // lines each.  One scratch slot (LDS executes a wave's accesses in order: row m + 1 is written after row m's reads were
+      // issued); the stores of row m are issued behind the packing and sums of row m + 1.
+      constexpr bool MRG = IG2_MRG && M16 && !DEFER && NF == 2 && TAPS != 1 && !PERM_EPI && !RAGGED;   // (the ragged instantiations spill 6 dwords with it)
+      // (plan_v2 keeps a concat split that falls between the two fragments of a wave -- split % 64 != 0 -- off these tilings)
+      constexpr bool mrg_done = MRG;
+      if constexpr (MRG) {
+        {
+          constexpr int P2 = 144;        // scratch pitch: 128 B of channels + 16 B pad
+          unsigned char* const sc2 = oscr + wave * (32 * P2);
+          static_assert(32 * P2 <= OSCR_SLOTS * 32 * 80, "the merged tile fits the wave's scratch");
+          u32x4 tv4[4];
+          int pm2 = -1;
+          auto store4 = [&](int mm) {
+            if (RAGGED && e_tyi * TH + wm * MF + mm >= p.h) return;
+            const int wlim = (RAGGED && (e_txi + 1) * TW > p.w) ? p.w - e_txi * TW : TW;
+            unsigned char* const fb = e_fb[0] + (size_t)mm * e_rowb[0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int chunk = lane + 64 * k, px = chunk >> 3, part = chunk & 7;
+              if (RAGGED && px >= wlim) continue;
+              *reinterpret_cast<u32x4*>(fb + (__umul24((unsigned)px, e_pstep[0]) + (unsigned)part * 16u)) = tv4[k];
+            }
+          };
+          if (STATS) {   // sums first, one channel fragment at a time, and out of the registers before the stores need them
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+#pragma unroll
+              for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                  const f32x2 av = {acc[m][q][i], acc[m][q][i + 1]};
+                  f32x2 sv = {s1[q][i], s1[q][i + 1]}, tv = {s2[q][i], s2[q][i + 1]};
+                  sv += av;
+                  tv = __builtin_elementwise_fma(av, av, tv);
+                  s1[q][i] = sv[0]; s1[q][i + 1] = sv[1]; s2[q][i] = tv[0]; s2[q][i + 1] = tv[1];
+                }
+              if (!WRES) stats_to_ws(q);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+              unsigned pk[8];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                pk[2 * g] = pack_bf16x2(acc[m][q][4 * g], acc[m][q][4 * g + 1]);
+                pk[2 * g + 1] = pack_bf16x2(acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]);
+              }
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {   // quarter g = 2*half + cc: pixel 16*half + (lane&15), channels 32q + 16cc + 4*(lane>>4) ..+3
+                const u32x2 v = {pk[2 * g], pk[2 * g + 1]};
+                *reinterpret_cast<u32x2*>(sc2 + (16 * (g >> 1) + (lane & 15)) * P2 + q * 64 + (16 * (g & 1) + 4 * (lane >> 4)) * 2) = v;
+              }
+            }
+            if (pm2 >= 0) store4(pm2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int chunk = lane + 64 * k;   // 256 chunks of 16 B: pixel = chunk / 8, part = chunk % 8
+              tv4[k] = *reinterpret_cast<const u32x4*>(sc2 + (chunk >> 3) * P2 + (chunk & 7) * 16);
+            }
+            pm2 = m;
+          }
+          store4(pm2);
+        }
+      }
       u32x4 tvp[2];
       int pm_ = -1, pq_ = 0, fidx = 0;
+      if constexpr (!mrg_done)
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
         // deconv bias from LDS (staged at kernel start): a global load here would put a vmcnt(0) --
@@ -1140,37 +1246,12 @@ __global__ void __launch_bounds__(512) igemm2_kernel(const Igemm2Params p) {
           }
         }
       }
-      if (!DEFER && !PERM_EPI) { frag_from_lds(tvp, (fidx - 1) & 1); frag_store(pm_, pq_, tvp); }
+      if (!DEFER && !PERM_EPI && !mrg_done) { frag_from_lds(tvp, (fidx - 1) & 1); frag_store(pm_, pq_, tvp); }
       if (DEFER) { set_item(img, tyi, txi, nbi); pend = true; }
       if (STATS && !WRES) {
-        float* ws = wg_stats + parity * (WM * 2 * NT);
+        if constexpr (!mrg_done) {
 #pragma unroll
-        for (int q = 0; q < NF; ++q) {
-          if constexpr (M16) {
-            // registers 4*(2*half + cc) + e: both pixel halves carry the same channels 16*cc + 4*(lane>>4) + e
-            float v1[8], v2[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { v1[k] = s1[q][k] + s1[q][8 + k]; v2[k] = s2[q][k] + s2[q][8 + k]; }
-            const float t1 = reduce16_scatter8(v1, lane);
-            const float t2 = reduce16_scatter8(v2, lane);
-            if ((lane & 1) == 0) {
-              const int reg = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-              const int cl = (wn * NF + q) * 32 + 16 * (reg >> 2) + 4 * (lane >> 4) + (reg & 3);
-              ws[(wm * 2 + 0) * NT + cl] = t1;
-              ws[(wm * 2 + 1) * NT + cl] = t2;
-            }
-          } else {
-          const float t1 = reduce32_scatter16(s1[q], lane);
-          const float t2 = reduce32_scatter16(s2[q], lane);
-          if ((lane & 1) == 0) {
-            const int reg = scatter16_reg_of_lane(lane);
-            const int cl = (wn * NF + q) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            ws[(wm * 2 + 0) * NT + cl] = t1;
-            ws[(wm * 2 + 1) * NT + cl] = t2;
-          }
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { s1[q][i] = 0.f; s2[q][i] = 0.f; }
+          for (int q = 0; q < NF; ++q) stats_to_ws(q);
         }
         pending_tile = tile; pending_nbi = nbi; parity ^= 1;
       }
@@ -1279,6 +1360,7 @@ static V2Plan plan_v2(const OctConvDesc* d) {
                  (d->in_mode == OCT_IN_S2D && d->out_mode == OCT_OUT_PLAIN && d->c1 == 0))));
   if (!pl.ok) return pl;
   pl.nt = d->cout == 32 ? 32 : (d->cout % 128 == 0 ? 128 : (d->cout % 64 == 0 ? 64 : 0));
+  if (pl.nt == 128 && d->split > 0 && (d->split % 64) != 0) pl.nt = 64;   // a wave's two channel fragments leave as one 128-B line (MRG): same destination
   if (pl.nt == 0) { pl.ok = false; return pl; }
   pl.wres = (d->taps == 9) && (cin == 32) && (d->cout == pl.nt) && pl.nt <= 64 && d->depth == 0;   // 3-D: three chunks per item
   pl.nblk = d->cout / pl.nt;
