@@ -416,6 +416,13 @@ int oct_index_scatter(int dtype, const void* v, const int64_t* idx, void* out, i
                       void* stream);
 int oct_index_gather(int dtype, const void* x, const int64_t* idx, void* v, int n, size_t npool, size_t plane, int c,
                      void* stream);
+/* The same pair by WINDOW CODE (library 0.2.2; the indices of ReLayNet's encoder -> decoder path never leave the library): code
+ * (n,h/k,w/k,c) uint8 = (iy - yo*k)*k + (ix - xo*k) of the winner oct_maxpool_idx_fwd would report.  oct_window_scatter writes the
+ * WHOLE (n, hp*k, wp*k, c) output (value at the code, zeros elsewhere: no zero-fill by the caller) = MaxUnpool2d forward and
+ * max-pool backward; oct_window_gather = MaxUnpool2d backward.  k <= 15.                                                      */
+int oct_maxpool_code_fwd(int dtype, const void* a, void* out, unsigned char* code, int n, int h, int w, int c, int k, void* stream);
+int oct_window_scatter(int dtype, const void* v, const unsigned char* code, void* out, int n, int hp, int wp, int c, int k, void* stream);
+int oct_window_gather(int dtype, const void* x, const unsigned char* code, void* v, int n, int hp, int wp, int c, int k, void* stream);
 
 /* MaxPool3d(2) of the cfg5 volumetric U-Net = oct_bn_relu_pool_fwd inside every slice, then the pairwise maximum of
  * consecutive slices: p2 (nslab, 2, m) -> out (nslab, m), m contiguous elements per slice ((h/2)*(w/2)*c).  Backward:

@@ -90,6 +90,9 @@ SIGNATURES = {
     "oct_maxpool_idx_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_index_scatter": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_int, c_void_p]),
     "oct_index_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_int, c_void_p]),
+    "oct_maxpool_code_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_window_scatter": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_window_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_pack_weights_batch": (c_int, [c_int, c_int, C.POINTER(PackJob), c_void_p]),
     "oct_conv_forward": (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvArgs), c_void_p]),
     "oct_conv_wgrad": (c_int, [C.POINTER(WgradDesc), C.POINTER(WgradArgs), c_void_p]),

@@ -591,6 +591,109 @@ extern "C" int oct_index_gather(int dtype, const void* x, const int64_t* idx, vo
   return oct_check_launch("index_gather");
 }
 
+// Pool / un-pool by WINDOW CODE (round 3; ReLayNet's encoder -> decoder path inside the network, where the indices never leave the
+// library): code[n, yo, xo, c] (one byte) = (iy - yo*k)*k + (ix - xo*k) of the winner -- what torch's int64 plane index says, for an
+// index that lies inside its own window (true of everything MaxPool2d returns).  The int64 form cost 8 B per pooled element in each
+// of its four uses and a scattered write into a tensor the caller had to zero first (fill + scatter: two passes over the big
+// tensor); by code the un-pooling is DENSE -- a thread owns a window, writes the value at its code and zeros at the other k*k - 1
+// positions, V channels at a time -- and needs no fill.  scatter = MaxUnpool2d forward = max-pool backward; gather = MaxUnpool2d
+// backward.  Same winners as oct_maxpool_idx_fwd (first maximum in row-major window order).
+template <typename T, int V>
+__global__ void maxpool_code_fwd_kernel(const T* __restrict__ a, T* __restrict__ out, unsigned char* __restrict__ code, int n, int ho,
+                                        int wo, int c, int k) {
+  const int G = c / V;
+  const size_t total = (size_t)n * ho * wo * G;
+  const int w = wo * k, h = ho * k;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = i % G; size_t p = i / G;
+    const int xo = p % wo; p /= wo; const int yo = p % ho; const int img = p / ho;
+    float m[V]; unsigned char arg[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { m[j] = -INFINITY; arg[j] = 0; }
+    for (int q = 0; q < k * k; ++q) {
+      const int iy = yo * k + q / k, ix = xo * k + q % k;
+      float v[V];
+      load_vec<T, V>(a + (((size_t)img * h + iy) * w + ix) * c + g * V, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) if (v[j] > m[j]) { m[j] = v[j]; arg[j] = (unsigned char)q; }
+    }
+    const size_t o = (((size_t)img * ho + yo) * wo + xo) * c + g * V;
+    store_vec<T, V>(out + o, m);
+#pragma unroll
+    for (int j = 0; j < V; ++j) code[o + j] = arg[j];
+  }
+}
+template <typename T, int V, bool SCATTER>
+__global__ void window_move_kernel(const T* __restrict__ src, const unsigned char* __restrict__ code, T* __restrict__ dst, int n, int ho,
+                                   int wo, int c, int k) {
+  const int G = c / V;
+  const size_t total = (size_t)n * ho * wo * G;
+  const int w = wo * k, h = ho * k;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = i % G; size_t p = i / G;
+    const int xo = p % wo; p /= wo; const int yo = p % ho; const int img = p / ho;
+    const size_t o = (((size_t)img * ho + yo) * wo + xo) * c + g * V;
+    unsigned char cd[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) cd[j] = code[o + j];
+    float v[V];
+    if (SCATTER) load_vec<T, V>(src + o, v);
+    else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = 0.f;
+    }
+    for (int q = 0; q < k * k; ++q) {
+      const size_t big = (((size_t)img * h + yo * k + q / k) * w + xo * k + q % k) * c + g * V;
+      float t[V];
+      if (SCATTER) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) t[j] = cd[j] == q ? v[j] : 0.f;
+        store_vec<T, V>(dst + big, t);
+      } else {
+        load_vec<T, V>(src + big, t);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = cd[j] == q ? t[j] : v[j];
+      }
+    }
+    if (!SCATTER) store_vec<T, V>(dst + o, v);
+  }
+}
+extern "C" int oct_maxpool_code_fwd(int dtype, const void* a, void* out, unsigned char* code, int n, int h, int w, int c, int k,
+                                    void* stream) {
+  OCT_CHECK(a && out && code && n > 0 && c > 0 && k > 0 && k <= 15 && h > 0 && w > 0 && h % k == 0 && w % k == 0, "oct_maxpool_code_fwd: bad args");
+  const int v = bk_vec(c);
+  const int blocks = bk_blocks((size_t)n * (h / k) * (w / k) * (c / v));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, V) hipLaunchKernelGGL((maxpool_code_fwd_kernel<T, V>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)a, \
+                                        (T*)out, code, n, h / k, w / k, c, k)
+  BK_DISPATCH("oct_maxpool_code_fwd");
+#undef LAUNCH
+  return oct_check_launch("maxpool_code_fwd");
+}
+extern "C" int oct_window_scatter(int dtype, const void* v_, const unsigned char* code, void* out, int n, int hp, int wp, int c, int k,
+                                  void* stream) {
+  OCT_CHECK(v_ && code && out && n > 0 && hp > 0 && wp > 0 && c > 0 && k > 0 && k <= 15, "oct_window_scatter: bad args");
+  const int v = bk_vec(c);
+  const int blocks = bk_blocks((size_t)n * hp * wp * (c / v));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, V) hipLaunchKernelGGL((window_move_kernel<T, V, true>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)v_, code, \
+                                        (T*)out, n, hp, wp, c, k)
+  BK_DISPATCH("oct_window_scatter");
+#undef LAUNCH
+  return oct_check_launch("window_scatter");
+}
+extern "C" int oct_window_gather(int dtype, const void* x, const unsigned char* code, void* v_, int n, int hp, int wp, int c, int k,
+                                 void* stream) {
+  OCT_CHECK(x && code && v_ && n > 0 && hp > 0 && wp > 0 && c > 0 && k > 0 && k <= 15, "oct_window_gather: bad args");
+  const int v = bk_vec(c);
+  const int blocks = bk_blocks((size_t)n * hp * wp * (c / v));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, V) hipLaunchKernelGGL((window_move_kernel<T, V, false>), dim3(blocks), dim3(BK_THREADS), 0, s, (const T*)x, code, \
+                                        (T*)v_, n, hp, wp, c, k)
+  BK_DISPATCH("oct_window_gather");
+#undef LAUNCH
+  return oct_check_launch("window_gather");
+}
 
 // ---------------------------------------------------------------------------------------------
 // MaxPool3d(2) = 2x2 pooling inside every slice (oct_bn_relu_pool_fwd) followed by THIS pairwise maximum over

@@ -480,6 +480,69 @@ class MaxUnpool(torch.autograd.Function):
         return None, None, dv, None
 
 
+class MaxPoolCode(torch.autograd.Function):
+    """MaxPoolIdx with the winner kept as a one-byte WINDOW CODE (dy*k + dx) instead of torch's int64 plane index: for the
+    encoder -> decoder path INSIDE a network, where the indices never reach the caller (oct_hip.h, oct_maxpool_code_fwd).
+    Backward = dense window scatter (no zero fill)."""
+
+    @staticmethod
+    def forward(ctx, dtype, k, a):
+        e = kernels(dtype)
+        a = a.contiguous()
+        n, h, w, c = a.shape
+        if h % k or w % k:
+            raise RuntimeError(f"max-pool window {k} does not divide {h}x{w}")
+        out = e._act(n, h // k, w // k, c, a.device)
+        code = torch.empty((n, h // k, w // k, c), dtype=torch.uint8, device=a.device)
+        L.check(L.lib().oct_maxpool_code_fwd(e.dt, a.data_ptr(), out.data_ptr(), code.data_ptr(), n, h, w, c, k, _stream()),
+                "oct_maxpool_code_fwd")
+        ctx.cfg = (dtype, k, (n, h, w, c))
+        ctx.save_for_backward(code)
+        ctx.mark_non_differentiable(code)
+        return out, code
+
+    @staticmethod
+    def backward(ctx, dout, _dcode):
+        dtype, k, (n, h, w, c) = ctx.cfg
+        (code,) = ctx.saved_tensors
+        e = kernels(dtype)
+        dout = dout.contiguous()
+        da = torch.empty((n, h, w, c), dtype=e.tdt, device=dout.device)
+        L.check(L.lib().oct_window_scatter(e.dt, dout.data_ptr(), code.data_ptr(), da.data_ptr(), n, h // k, w // k, c, k, _stream()),
+                "oct_window_scatter")
+        return None, None, da
+
+
+class MaxUnpoolCode(torch.autograd.Function):
+    """MaxUnpool2d(k, k) from window codes: the whole output is written (value at the code, zeros elsewhere); backward = gather."""
+
+    @staticmethod
+    def forward(ctx, dtype, k, v, code):
+        e = kernels(dtype)
+        v, code = v.contiguous(), code.contiguous()
+        n, hp, wp, c = v.shape
+        if code.shape != v.shape or code.dtype != torch.uint8:
+            raise RuntimeError(f"window codes must be uint8 of the pooled shape {tuple(v.shape)}, got {code.dtype} {tuple(code.shape)}")
+        out = torch.empty((n, hp * k, wp * k, c), dtype=e.tdt, device=v.device)
+        L.check(L.lib().oct_window_scatter(e.dt, v.data_ptr(), code.data_ptr(), out.data_ptr(), n, hp, wp, c, k, _stream()),
+                "oct_window_scatter")
+        ctx.cfg = (dtype, k)
+        ctx.save_for_backward(code)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dtype, k = ctx.cfg
+        (code,) = ctx.saved_tensors
+        e = kernels(dtype)
+        dout = dout.contiguous()
+        n, hp, wp, c = code.shape
+        dv = e._act(n, hp, wp, c, dout.device)
+        L.check(L.lib().oct_window_gather(e.dt, dout.data_ptr(), code.data_ptr(), dv.data_ptr(), n, hp, wp, c, k, _stream()),
+                "oct_window_gather")
+        return None, None, dv, None
+
+
 class BilinearUp(torch.autograd.Function):
     """x`factor` bilinear up-sampling with align_corners=True."""
 

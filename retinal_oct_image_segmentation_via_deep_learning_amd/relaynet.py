@@ -50,6 +50,11 @@ class BasicBlock(HipModule):
         return self._out(self.nhwc(self._in(input)))
 
 
+# OCT_POOL_CODES=0: the network's internal pool -> un-pool path on torch's int64 indices (the public block API always uses them)
+import os as _os
+_WINDOW_CODES = [_os.environ.get("OCT_POOL_CODES", "1") != "0"]
+
+
 class EncoderBlock(BasicBlock):
     def __init__(self, params, compute_dtype="bf16"):
         super().__init__(params, compute_dtype)
@@ -58,9 +63,15 @@ class EncoderBlock(BasicBlock):
         self._k = params["pool"]
         self.maxpool = nn.MaxPool2d(kernel_size=params["pool"], stride=params["stride_pool"], return_indices=True)
 
-    def nhwc(self, a):
+    def nhwc(self, a, codes=False):
+        """codes=True (inside ReLayNet.forward, where the indices only travel to the matching DecoderBlock): one-byte window codes
+        instead of torch's int64 plane indices (ops.MaxPoolCode) -- the same winners, an eighth of the index traffic, and a dense
+        un-pooling that needs no zero fill."""
         out_block = BasicBlock.nhwc(self, a)
-        pooled, idx = ops.MaxPoolIdx.apply(self.compute_dtype, self._k, out_block)
+        if codes:
+            pooled, idx = ops.MaxPoolCode.apply(self.compute_dtype, self._k, out_block)
+        else:
+            pooled, idx = ops.MaxPoolIdx.apply(self.compute_dtype, self._k, out_block)
         return pooled, out_block, idx
 
     def forward(self, input):
@@ -77,7 +88,10 @@ class DecoderBlock(BasicBlock):
         self.unpool = nn.MaxUnpool2d(kernel_size=params["pool"], stride=params["stride_pool"])
 
     def nhwc(self, a, out_block, idx):
-        unpool = ops.MaxUnpool.apply(self.compute_dtype, self._k, a, idx)
+        if idx.dtype == torch.uint8:     # window codes of an EncoderBlock.nhwc(codes=True)
+            unpool = ops.MaxUnpoolCode.apply(self.compute_dtype, self._k, a, idx)
+        else:
+            unpool = ops.MaxUnpool.apply(self.compute_dtype, self._k, a, idx)
         if unpool.shape[:3] != out_block.shape[:3]:
             # torch.cat((out_block, unpool), dim=1), ReLayNet_2017.py:187
             raise RuntimeError(f"Sizes of tensors must match except in dimension 1. Expected size {out_block.shape[1]}x"
@@ -132,9 +146,10 @@ class ReLayNet(HipModule):
                                f"{input.shape[3]} is not divisible by {self._div} (three {self._div ** (1 / 3):.0f}x poolings "
                                f"followed by as many unpoolings)")
         a = self._in(input)
-        e1, out1, ind1 = self.encode1.nhwc(a)
-        e2, out2, ind2 = self.encode2.nhwc(e1)
-        e3, out3, ind3 = self.encode3.nhwc(e2)
+        codes = _WINDOW_CODES[0]
+        e1, out1, ind1 = self.encode1.nhwc(a, codes)
+        e2, out2, ind2 = self.encode2.nhwc(e1, codes)
+        e3, out3, ind3 = self.encode3.nhwc(e2, codes)
         bn = self.bottleneck.nhwc(e3)
         d3 = self.decode1.nhwc(bn, out3, ind3)
         d2 = self.decode2.nhwc(d3, out2, ind2)

@@ -192,3 +192,38 @@ def test_deterministic_mode_matches_atomics_on_7x3_weight_gradients(golden_dir, 
     for k in grads[False]:
         a, b = grads[False][k].double(), grads[True][k].double()
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-6), k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape,k", [((2, 12, 16, 8), 2), ((1, 9, 6, 16), 3), ((3, 4, 4, 5), 2)])
+def test_window_code_pool_unpool_equals_the_index_form(dtype, shape, k):
+    """ops.MaxPoolCode / MaxUnpoolCode (one-byte window codes inside the network) against ops.MaxPoolIdx / MaxUnpool (torch's
+    int64 plane indices, ReLayNet_2017.py:174-188) and against torch itself: same winners under ties (first maximum in row-major
+    window order), same un-pooled tensor without a zero fill, same gradients -- bit for bit."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(h * 131 + w + k)
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    a = torch.randint(-3, 4, shape, generator=g).to(tdt).cuda()          # few distinct values: plenty of ties
+    a1, a2 = a.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    p1, idx = ops.MaxPoolIdx.apply(dtype, k, a1)
+    p2, code = ops.MaxPoolCode.apply(dtype, k, a2)
+    assert torch.equal(p1, p2) and code.dtype == torch.uint8
+    yo = torch.arange(h // k, device="cuda").view(1, -1, 1, 1)
+    xo = torch.arange(w // k, device="cuda").view(1, 1, -1, 1)
+    assert torch.equal((yo * k + code.long() // k) * w + xo * k + code.long() % k, idx), "codes name torch's winners"
+    tp, tidx = F.max_pool2d(a.float().permute(0, 3, 1, 2), k, k, return_indices=True)
+    assert torch.equal(tidx.permute(0, 2, 3, 1), idx) and torch.equal(tp.permute(0, 2, 3, 1).to(tdt), p1)
+    v = torch.randint(-4, 5, p1.shape, generator=g).to(tdt).cuda()
+    v1, v2 = v.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    u1 = ops.MaxUnpool.apply(dtype, k, v1, idx)
+    u2 = ops.MaxUnpoolCode.apply(dtype, k, v2, code)
+    assert torch.equal(u1, u2) and not torch.isnan(u2.float()).any()
+    r = torch.randint(-2, 3, u1.shape, generator=g).to(tdt).cuda()
+    (u1.float() * r.float()).sum().backward()
+    (u2.float() * r.float()).sum().backward()
+    assert torch.equal(v1.grad, v2.grad)
+    rp = torch.randint(-2, 3, p1.shape, generator=g).to(tdt).cuda()
+    (p1.float() * rp.float()).sum().backward()
+    (p2.float() * rp.float()).sum().backward()
+    assert torch.equal(a1.grad, a2.grad)
