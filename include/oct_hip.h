@@ -406,6 +406,16 @@ int oct_affine_prelu_fwd(int dtype, const void* y, const float* scale, const flo
                          void* out, size_t npix, int c, void* stream);
 int oct_affine_prelu_bwd(int dtype, const void* dout, const void* y, const float* scale, const float* shift,
                          const float* alpha, void* dz, float* dalpha, size_t npix, int c, void* stream);
+/* The same backward WITHOUT the dz tensor (library 0.2.2): the two BatchNorm-backward passes re-derive dz = dout * (z > 0 ? 1 : alpha)
+ * themselves -- oct_dact_bn_reduce_prelu (sums for oct_bn_bwd_finalize, dalpha[0] += ...; partial rows as oct_dact_bn_reduce_blocks
+ * (n, h, w, c, 0)) and oct_bn_bwd_apply_prelu_to (dst = k0*dz + k1*y + k2) -- bit-identical to oct_affine_prelu_bwd followed by the
+ * plain passes.  oct_prelu_bn_fused_ok: c % 8 == 0 with 256 % (c/8) == 0.                                                  */
+int oct_prelu_bn_fused_ok(int dtype, int c);
+int oct_dact_bn_reduce_prelu(int dtype, const void* da, const void* y, const float* scale, const float* shift, const float* alpha,
+                             const float* mean, const float* invstd, float* partials, float* dalpha, int n, int h, int w, int c,
+                             void* stream);
+int oct_bn_bwd_apply_prelu_to(int dtype, void* dst, const void* da, const void* y, const float* coef, const float* scale,
+                              const float* shift, const float* alpha, size_t npix, int c, void* stream);
 /* EncoderBlock :174-179, nn.MaxPool2d(k, k, return_indices=True): out (n,h/k,w/k,c) and idx (same shape, int64) holding
  * torch's index of the winner inside its (n, c) input plane, iy*w + ix; first maximum in row-major window order.      */
 int oct_maxpool_idx_fwd(int dtype, const void* a, void* out, int64_t* idx, int n, int h, int w, int c, int k, void* stream);

@@ -90,6 +90,11 @@ SIGNATURES = {
     "oct_maxpool_idx_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_index_scatter": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_int, c_void_p]),
     "oct_index_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_int, c_void_p]),
+    "oct_prelu_bn_fused_ok": (c_int, [c_int, c_int]),
+    "oct_dact_bn_reduce_prelu": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_int, c_int, c_int, c_void_p]),
+    "oct_bn_bwd_apply_prelu_to": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
+                                          c_void_p]),
     "oct_maxpool_code_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_window_scatter": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oct_window_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

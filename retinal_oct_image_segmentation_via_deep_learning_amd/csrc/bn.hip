@@ -427,6 +427,127 @@ __global__ void __launch_bounds__(EW_THREADS) dact_bn_reduce_flat_kernel(
   block_reduce_store<V>(s1, s2, gi, G, c, partials, true, nullptr);
 }
 
+// PReLU in place of the ReLU mask (ReLayNet's BasicBlock, ReLayNet_2017.py:164-168: conv -> BN -> nn.PReLU()): dz = dA * (z > 0 ? 1 :
+// alpha) is re-derived in BOTH BatchNorm-backward passes instead of being written by a pass of its own (oct_affine_prelu_bwd: read dA,
+// y, write dz -- three of the eight tensor passes of the layer's backward, 2.1 of ReLayNet's 18.4 ms per step).  The value that
+// enters the sums and the apply is rounded to the storage type exactly where the separate pass stored it, so the results are
+// bit-identical to the three-kernel flow; d(alpha) = sum dA * z * [z <= 0] rides on the reduction (one atomic per wave, as before).
+template <typename T, int U>
+__global__ void __launch_bounds__(EW_THREADS) dact_bn_reduce_prelu_flat_kernel(
+    const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ alpha, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ partials, float* __restrict__ dalpha, size_t total, int c) {
+  constexpr int V = 8;
+  const int G = c / V, gi = threadIdx.x % G;
+  float sc[V], sh[V], mu[V], is[V], s1[V], s2[V];
+  ldv<float, V>(scale + gi * V, sc); ldv<float, V>(shift + gi * V, sh);
+  ldv<float, V>(mean + gi * V, mu); ldv<float, V>(invstd + gi * V, is);
+  const float al = alpha[0];
+  float sa = 0.f;
+#pragma unroll
+  for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const size_t stride = (size_t)gridDim.x * EW_THREADS;
+  size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  auto one = [&](const float (&yv)[V], const float (&dv)[V]) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float z = fmaf(yv[j], sc[j], sh[j]);
+      float gv = dv[j];
+      if (!(z > 0.f)) { sa = fmaf(dv[j], z, sa); gv = to_f32(from_f32<T>(dv[j] * al)); }   // the slope branch at z == 0 (ATen)
+      s1[j] += gv;
+      s2[j] += gv * ((yv[j] - mu[j]) * is[j]);
+    }
+  };
+  for (; i + (U - 1) * stride < total; i += U * stride) {
+    float yv[U][V], dv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { load_vec_nt<T, V>(y + (i + u * stride) * V, yv[u]); load_vec_nt<T, V>(da + (i + u * stride) * V, dv[u]); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(yv[u], dv[u]);
+  }
+  for (; i < total; i += stride) {
+    float yv[V], dv[V];
+    ldv<T, V>(y + i * V, yv); ldv<T, V>(da + i * V, dv);
+    one(yv, dv);
+  }
+  sa = wave_sum(sa);
+  if ((threadIdx.x & 63) == 0) atomicAdd(dalpha, sa);
+  block_reduce_store<V>(s1, s2, gi, G, c, partials, true, nullptr);
+}
+template <typename T, int U>
+__global__ void __launch_bounds__(EW_THREADS) bn_bwd_apply_prelu_flat_kernel(T* dst, const T* g, const T* __restrict__ y,
+                                                                            const float* __restrict__ coef,
+                                                                            const float* __restrict__ scale,
+                                                                            const float* __restrict__ shift,
+                                                                            const float* __restrict__ alpha, size_t total, int c) {
+  constexpr int V = 8;
+  const int G = c / V, gi = threadIdx.x % G;
+  float k0[V], k1[V], k2[V], sc[V], sh[V];
+  ldv<float, V>(coef + gi * V, k0); ldv<float, V>(coef + c + gi * V, k1); ldv<float, V>(coef + 2 * c + gi * V, k2);
+  ldv<float, V>(scale + gi * V, sc); ldv<float, V>(shift + gi * V, sh);
+  const float al = alpha[0];
+  const size_t stride = (size_t)gridDim.x * EW_THREADS;
+  size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  auto one = [&](float (&gv)[V], const float (&yv)[V], size_t at) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      if (!(fmaf(yv[j], sc[j], sh[j]) > 0.f)) gv[j] = to_f32(from_f32<T>(gv[j] * al));
+      gv[j] = fmaf(k0[j], gv[j], fmaf(k1[j], yv[j], k2[j]));
+    }
+    store_vec_nt<T, V>(dst + at * V, gv);
+  };
+  for (; i + (U - 1) * stride < total; i += U * stride) {
+    float gv[U][V], yv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { load_vec_nt<T, V>(g + (i + u * stride) * V, gv[u]); load_vec_nt<T, V>(y + (i + u * stride) * V, yv[u]); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(gv[u], yv[u], i + u * stride);
+  }
+  for (; i < total; i += stride) {
+    float gv[V], yv[V];
+    ldv<T, V>(g + i * V, gv); ldv<T, V>(y + i * V, yv);
+    one(gv, yv, i);
+  }
+}
+// 1 when the two entry points below take this channel count (else: oct_affine_prelu_bwd + the plain passes)
+extern "C" int oct_prelu_bn_fused_ok(int dtype, int c) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("OCT_PRELU_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
+  return (on && (dtype == OCT_DT_BF16 || dtype == OCT_DT_F32) && c > 0 && vec_width(c) == 8 && lane_mapping_ok(c, 8)) ? 1 : 0;
+}
+// partials: [oct_dact_bn_reduce_blocks(n, h, w, c, 0)][2][c]; dalpha: float[1], zeroed by the caller
+extern "C" int oct_dact_bn_reduce_prelu(int dtype, const void* da, const void* y, const float* scale, const float* shift,
+                                        const float* alpha, const float* mean, const float* invstd, float* partials,
+                                        float* dalpha, int n, int h, int w, int c, void* stream) {
+  OCT_CHECK(da && y && scale && shift && alpha && mean && invstd && partials && dalpha, "oct_dact_bn_reduce_prelu: null pointer");
+  OCT_CHECK(n > 0 && h > 0 && w > 0 && oct_prelu_bn_fused_ok(dtype, c), "oct_dact_bn_reduce_prelu: shape / dtype not supported (oct_prelu_bn_fused_ok)");
+  const int blocks = oct_dact_bn_reduce_blocks(n, h, w, c, 0);
+  const size_t total = (size_t)n * h * w * (c / 8);
+  hipStream_t s = as_stream(stream);
+  if (dtype == OCT_DT_BF16)
+    hipLaunchKernelGGL((dact_bn_reduce_prelu_flat_kernel<bf16_t, 4>), dim3(blocks), dim3(EW_THREADS), 0, s, (const bf16_t*)da,
+                       (const bf16_t*)y, scale, shift, alpha, mean, invstd, partials, dalpha, total, c);
+  else
+    hipLaunchKernelGGL((dact_bn_reduce_prelu_flat_kernel<float, 2>), dim3(blocks), dim3(EW_THREADS), 0, s, (const float*)da,
+                       (const float*)y, scale, shift, alpha, mean, invstd, partials, dalpha, total, c);
+  return oct_check_launch("dact_bn_reduce_prelu");
+}
+extern "C" int oct_bn_bwd_apply_prelu_to(int dtype, void* dst, const void* da, const void* y, const float* coef, const float* scale,
+                                         const float* shift, const float* alpha, size_t npix, int c, void* stream) {
+  OCT_CHECK(dst && da && y && coef && scale && shift && alpha && npix > 0, "oct_bn_bwd_apply_prelu_to: bad args");
+  OCT_CHECK(oct_prelu_bn_fused_ok(dtype, c), "oct_bn_bwd_apply_prelu_to: shape / dtype not supported (oct_prelu_bn_fused_ok)");
+  const int blocks = ew_blocks(npix, c / 8);
+  const size_t total = npix * (size_t)(c / 8);
+  hipStream_t s = as_stream(stream);
+  if (dtype == OCT_DT_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_prelu_flat_kernel<bf16_t, 1>), dim3(blocks), dim3(EW_THREADS), 0, s, (bf16_t*)dst,
+                       (const bf16_t*)da, (const bf16_t*)y, coef, scale, shift, alpha, total, c);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_prelu_flat_kernel<float, 1>), dim3(blocks), dim3(EW_THREADS), 0, s, (float*)dst,
+                       (const float*)da, (const float*)y, coef, scale, shift, alpha, total, c);
+  return oct_check_launch("bn_bwd_apply_prelu");
+}
+
 static bool pool_coalesced_ok(int n, int h, int w, int c) {
   return vec_width(c) == 8 && c <= 256 && ((c / 8) & (c / 8 - 1)) == 0 && (size_t)n * (h / 2) * w * (c / 8) < (1u << 31);
 }

@@ -289,6 +289,7 @@ class ConvAffineAct(torch.autograd.Function):
         kd = dict(kh=kk[0], kw=kk[1]) if kk else {}
         dalpha = None
         fuse_bias = False
+        prelu_fused = False
         e = kernels(dtype)
         lib = L.lib()
         n, h, wd, c0 = x0.shape
@@ -301,6 +302,11 @@ class ConvAffineAct(torch.autograd.Function):
             raise RuntimeError("backward through an eval-mode BatchNorm whose forward ran under no_grad()")
         if lazy == "relu":
             dz = dout       # dA: the mask [scale*y + shift > 0] is applied inside the two BN-backward passes
+        elif act == L.ACT_PRELU and bn is not None and lib.oct_prelu_bn_fused_ok(e.dt, cout) == 1:
+            # dz = dout * (z > 0 ? 1 : alpha) is re-derived inside the two BatchNorm-backward passes (never written)
+            prelu_fused = True
+            dz = dout
+            dalpha = torch.zeros(1, dtype=torch.float32, device=dev)
         elif act == L.ACT_PRELU:
             dz = torch.empty_like(dout)
             dalpha = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -320,13 +326,19 @@ class ConvAffineAct(torch.autograd.Function):
             # sums of dz and dz*xhat: the reduction kernel of the fused path with its ReLU mask held open
             nblk = lib.oct_dact_bn_reduce_blocks(n, h, wd, cout, 0)
             partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
-            if lazy == "relu":
-                msc, msh = scale, shift
-            else:       # dz is already masked: hold the reduction kernel's ReLU mask open (0*y + 1 > 0)
-                msc, msh = e._const(0.0, cout, dev), e._const(1.0, cout, dev)
-            L.check(lib.oct_dact_bn_reduce(e.dt, dz.data_ptr(), None, y.data_ptr(), msc.data_ptr(), msh.data_ptr(),
-                                           mean.data_ptr(), invstd.data_ptr(), None, partials.data_ptr(), n, h, wd, cout,
-                                           _stream()), "oct_dact_bn_reduce")
+            if prelu_fused:
+                L.check(lib.oct_dact_bn_reduce_prelu(e.dt, dz.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                     alpha.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
+                                                     dalpha.data_ptr(), n, h, wd, cout, _stream()), "oct_dact_bn_reduce_prelu")
+                dalpha = dalpha.reshape(alpha.shape)
+            else:
+                if lazy == "relu":
+                    msc, msh = scale, shift
+                else:       # dz is already masked: hold the reduction kernel's ReLU mask open (0*y + 1 > 0)
+                    msc, msh = e._const(0.0, cout, dev), e._const(1.0, cout, dev)
+                L.check(lib.oct_dact_bn_reduce(e.dt, dz.data_ptr(), None, y.data_ptr(), msc.data_ptr(), msh.data_ptr(),
+                                               mean.data_ptr(), invstd.data_ptr(), None, partials.data_ptr(), n, h, wd, cout,
+                                               _stream()), "oct_dact_bn_reduce")
             dgamma, dbeta = torch.empty_like(scale), torch.empty_like(scale)
             coef = torch.empty((3, cout), dtype=torch.float32, device=dev)
             L.check(lib.oct_bn_bwd_finalize(partials.data_ptr(), nblk, cout, float(npix), gamma.data_ptr(),
@@ -336,10 +348,15 @@ class ConvAffineAct(torch.autograd.Function):
                 coef[1:].zero_()
             # dz stays intact when somebody else still reads it (the residual branch's gradient, autograd's own buffer)
             dy = torch.empty_like(dz) if (has_res or dz is dout) else dz
-            L.check(lib.oct_bn_bwd_apply_to(e.dt, dy.data_ptr(), dz.data_ptr(), y.data_ptr(), coef.data_ptr(),
-                                            scale.data_ptr() if lazy == "relu" else None,
-                                            shift.data_ptr() if lazy == "relu" else None,
-                                            npix, cout, _stream()), "oct_bn_bwd_apply_to")
+            if prelu_fused:
+                L.check(lib.oct_bn_bwd_apply_prelu_to(e.dt, dy.data_ptr(), dz.data_ptr(), y.data_ptr(), coef.data_ptr(),
+                                                      scale.data_ptr(), shift.data_ptr(), alpha.data_ptr(), npix, cout, _stream()),
+                        "oct_bn_bwd_apply_prelu_to")
+            else:
+                L.check(lib.oct_bn_bwd_apply_to(e.dt, dy.data_ptr(), dz.data_ptr(), y.data_ptr(), coef.data_ptr(),
+                                                scale.data_ptr() if lazy == "relu" else None,
+                                                shift.data_ptr() if lazy == "relu" else None,
+                                                npix, cout, _stream()), "oct_bn_bwd_apply_to")
             if has_bias:
                 # train mode: a bias in front of BatchNorm cancels in (y - mean); frozen statistics: d(bias) = sum dy = k0 * sum dz
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev) if train_bn else coef[0] * partials[:, 0, :].sum(0)

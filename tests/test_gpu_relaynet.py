@@ -227,3 +227,49 @@ def test_window_code_pool_unpool_equals_the_index_form(dtype, shape, k):
     (p1.float() * rp.float()).sum().backward()
     (p2.float() * rp.float()).sum().backward()
     assert torch.equal(a1.grad, a2.grad)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 12, 20, 64), (1, 7, 9, 8), (3, 16, 16, 128)])
+def test_prelu_inside_the_batchnorm_backward_passes_equals_the_separate_pass(dtype, shape):
+    """oct_dact_bn_reduce_prelu + oct_bn_bwd_apply_prelu_to (dz = dA * (z > 0 ? 1 : alpha) re-derived in both BatchNorm-backward
+    passes, never written) against oct_affine_prelu_bwd followed by the plain passes: partial sums and dy BIT-identical (the value
+    that enters them is rounded to the storage type where the separate pass stored it), d(alpha) equal up to the order of its
+    fp32 atomics."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import _lib as L
+    lib = L.lib()
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + c)
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    dt = L.DT_F32 if dtype == "f32" else L.DT_BF16
+    assert lib.oct_prelu_bn_fused_ok(dt, c) == 1 and lib.oct_prelu_bn_fused_ok(dt, 12) == 0
+    y = torch.randn(shape, generator=g).to(tdt).cuda()
+    da = torch.randn(shape, generator=g).to(tdt).cuda()
+    sc = (torch.rand(c, generator=g) + 0.5).cuda(); sh = (torch.randn(c, generator=g) * 0.3).cuda()
+    mean = (torch.randn(c, generator=g) * 0.1).cuda(); invstd = (torch.rand(c, generator=g) + 0.5).cuda()
+    alpha = torch.tensor([0.25], device="cuda")
+    coef = torch.randn(3, c, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    npix = n * h * w
+    nblk = lib.oct_dact_bn_reduce_blocks(n, h, w, c, 0)
+    # separate pass, then the plain reduction (mask held open) and apply
+    dz = torch.empty_like(da); dal1 = torch.zeros(1, device="cuda")
+    L.check(lib.oct_affine_prelu_bwd(dt, da.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), alpha.data_ptr(), dz.data_ptr(),
+                                     dal1.data_ptr(), npix, c, st))
+    p1 = torch.full((nblk, 2, c), float("nan"), device="cuda")
+    zero, one = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    L.check(lib.oct_dact_bn_reduce(dt, dz.data_ptr(), None, y.data_ptr(), zero.data_ptr(), one.data_ptr(), mean.data_ptr(),
+                                   invstd.data_ptr(), None, p1.data_ptr(), n, h, w, c, st))
+    dy1 = torch.empty_like(da)
+    L.check(lib.oct_bn_bwd_apply_to(dt, dy1.data_ptr(), dz.data_ptr(), y.data_ptr(), coef.data_ptr(), None, None, npix, c, st))
+    # fused
+    p2 = torch.full((nblk, 2, c), float("nan"), device="cuda"); dal2 = torch.zeros(1, device="cuda")
+    L.check(lib.oct_dact_bn_reduce_prelu(dt, da.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), alpha.data_ptr(),
+                                         mean.data_ptr(), invstd.data_ptr(), p2.data_ptr(), dal2.data_ptr(), n, h, w, c, st))
+    dy2 = torch.full_like(da, float("nan"))
+    L.check(lib.oct_bn_bwd_apply_prelu_to(dt, dy2.data_ptr(), da.data_ptr(), y.data_ptr(), coef.data_ptr(), sc.data_ptr(),
+                                          sh.data_ptr(), alpha.data_ptr(), npix, c, st))
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2), "BatchNorm-backward partial sums"
+    assert torch.equal(dy1, dy2), "dy"
+    torch.testing.assert_close(dal1, dal2, rtol=1e-4, atol=1e-4)
