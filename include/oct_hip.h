@@ -278,6 +278,9 @@ int oct_rowdot_fwd(int dtype, const void* x, const float* w, void* y, float* sta
 int oct_rowdot_bwd_data(int dtype, const void* dy, const float* w, void* dx, size_t npix, int c, int k, void* stream);
 int oct_rowdot_bwd_weight(int dtype, const void* dy, const void* x, float* dw, float* partials, size_t npix, int c, int k,
                           int accumulate, void* stream);
+/* + the bias gradient dbias[k] (+)= sum_pix dy[pix][k] from the same pass (library 0.2.2); partials: [oct_rowdot_blocks][k*c + k] */
+int oct_rowdot_bwd_weight_bias(int dtype, const void* dy, const void* x, float* dw, float* dbias, float* partials, size_t npix, int c,
+                               int k, int accumulate, void* stream);
 
 /* per-channel sum over pixels of an NHWC tensor (bias gradient of ConvTranspose2d) */
 int oct_channel_sum(int dtype, const void* x, float* out, size_t npix, int c, int accumulate,

@@ -132,6 +132,8 @@ SIGNATURES = {
     "oct_rowdot_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "oct_rowdot_bwd_data": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "oct_rowdot_bwd_weight": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "oct_rowdot_bwd_weight_bias": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
+                                           c_void_p]),
     "oct_head_blocks": (c_int, [C.POINTER(HeadDesc)]),
     "oct_head_forward": (c_int, [C.POINTER(HeadDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -290,6 +290,7 @@ class ConvAffineAct(torch.autograd.Function):
         dalpha = None
         fuse_bias = False
         prelu_fused = False
+        rowdot_bias = False
         e = kernels(dtype)
         lib = L.lib()
         n, h, wd, c0 = x0.shape
@@ -367,15 +368,22 @@ class ConvAffineAct(torch.autograd.Function):
                 # kernel instead of a separate pass over dY (the direct first-layer kernel has no such path: cin = 1, 3 ...)
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
                 fuse_bias = True
+            elif has_bias and ctx.rowdot:
+                rowdot_bias = True      # rides on the streaming weight-gradient pass below
+                dcb = torch.empty(cout, dtype=torch.float32, device=dev)
             elif has_bias:
                 dcb = torch.empty(cout, dtype=torch.float32, device=dev)
                 L.check(lib.oct_channel_sum(e.dt, dy.data_ptr(), dcb.data_ptr(), npix, cout, 0, _stream()),
                         "oct_channel_sum")
         if ctx.rowdot:
             dw = torch.empty_like(w)
-            scratch = torch.empty((lib.oct_rowdot_blocks(npix, c0), cout * c0), dtype=torch.float32, device=dev)
-            L.check(lib.oct_rowdot_bwd_weight(e.dt, dy.data_ptr(), x0.data_ptr(), dw.data_ptr(), scratch.data_ptr(), npix, c0,
-                                              cout, 0, _stream()), "oct_rowdot_bwd_weight")
+            scratch = torch.empty((lib.oct_rowdot_blocks(npix, c0), cout * c0 + cout), dtype=torch.float32, device=dev)
+            if rowdot_bias:
+                L.check(lib.oct_rowdot_bwd_weight_bias(e.dt, dy.data_ptr(), x0.data_ptr(), dw.data_ptr(), dcb.data_ptr(),
+                                                       scratch.data_ptr(), npix, c0, cout, 0, _stream()), "oct_rowdot_bwd_weight_bias")
+            else:
+                L.check(lib.oct_rowdot_bwd_weight(e.dt, dy.data_ptr(), x0.data_ptr(), dw.data_ptr(), scratch.data_ptr(), npix, c0,
+                                                  cout, 0, _stream()), "oct_rowdot_bwd_weight")
             d0 = None
             if ctx.needs_input_grad[3]:
                 d0 = e._act(n, h, wd, c0, dev)

@@ -191,6 +191,14 @@ def test_rowdot_kernels_match_numpy(dtype, c, k):
     SC = torch.empty((nblk, k * c), dtype=torch.float32, device="cuda")
     L.check(lib.oct_rowdot_bwd_weight(dt, DY.data_ptr(), X.data_ptr(), DW.data_ptr(), SC.data_ptr(), npix, c, k, 0, st))
     assert np.array_equal(DW.cpu().numpy(), dy.T @ x)
+    # the same pass with the bias gradient riding on it (class heads): dw unchanged, db = column sums of dy, accumulate mode adds
+    SCB = torch.empty((nblk, k * c + k), dtype=torch.float32, device="cuda")
+    DW2 = torch.full((k, c), float("nan"), dtype=torch.float32, device="cuda")
+    DB = torch.full((k,), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(lib.oct_rowdot_bwd_weight_bias(dt, DY.data_ptr(), X.data_ptr(), DW2.data_ptr(), DB.data_ptr(), SCB.data_ptr(), npix, c, k, 0, st))
+    assert np.array_equal(DW2.cpu().numpy(), dy.T @ x) and np.array_equal(DB.cpu().numpy(), dy.sum(0))
+    L.check(lib.oct_rowdot_bwd_weight_bias(dt, DY.data_ptr(), X.data_ptr(), DW2.data_ptr(), DB.data_ptr(), SCB.data_ptr(), npix, c, k, 1, st))
+    assert np.array_equal(DB.cpu().numpy(), 2 * dy.sum(0))
     L.check(lib.oct_rowdot_bwd_weight(dt, DY.data_ptr(), X.data_ptr(), DW.data_ptr(), SC.data_ptr(), npix, c, k, 1, st))
     assert np.array_equal(DW.cpu().numpy(), 2 * (dy.T @ x))
 
