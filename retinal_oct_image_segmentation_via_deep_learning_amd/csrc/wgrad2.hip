@@ -86,8 +86,11 @@ __device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* first, const uns
 template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false, bool RSH = false>
 __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
   constexpr int TW = 32;
-  constexpr int HALO = (TAPS == 9) ? 1 : 0;
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  // TAPS = 9: 3x3; TAPS = 3: one row of three (the seventh row of ReLayNet's 7x3, always row-shifted: RSH); TAPS = 1: 1x1
+  constexpr int HALO = (TAPS != 1) ? 1 : 0;        // columns
+  constexpr int HALO_Y = (TAPS == 9) ? 1 : 0;      // rows
+  static_assert(TAPS != 3 || RSH, "the 1x3 kernel exists as a row group of a taller one");
+  constexpr int LH = TH + 2 * HALO_Y, LW = TW + 2 * HALO;
   constexpr int NPI = LH * LW, NPD = TH * TW;          // pixels of the input / dY tile
   constexpr int INB = NPI * 64, DYB = NPD * 64;        // bytes per 32-channel block
   constexpr int STAGEB = IB * INB + CB * DYB;
@@ -180,9 +183,9 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
       if constexpr (RSH) lyv[j] = ly;
       // bottom / right flags against the LAST tile row / column of the image (see igemm2.hip): the halo
       // row / column for whole tiles, everything beyond H, W for a ragged size
-      const int ylast = p.h - (p.tiles_y - 1) * TH + HALO, xlast = p.w - (p.tiles_x - 1) * TW + HALO;
+      const int ylast = p.h - (p.tiles_y - 1) * TH + HALO_Y, xlast = p.w - (p.tiles_x - 1) * TW + HALO;
       unsigned c = pix >= NPI ? 16u : 0u;
-      if (HALO) c |= ((!RSH && ly == 0) ? 1u : 0u) | (lx == 0 ? 4u : 0u);
+      if (HALO) c |= ((!RSH && HALO_Y && ly == 0) ? 1u : 0u) | (lx == 0 ? 4u : 0u);
       c |= ((!RSH && ly >= ylast) ? 2u : 0u) | (lx >= xlast ? 8u : 0u);
       code[j] = c | (SWZ ? (unsigned)(((lx >> 3) & 1) << 1) << 8 : 0u);   // bits 8-9: chunk swizzle of this pixel
     }
@@ -447,7 +450,7 @@ __global__ void __launch_bounds__(512) wgrad2_kernel(const Wgrad2Params p) {
     constexpr int NK = ROWS * 2;                 // k-steps (16 pixels) of this wave per stage
     auto a_off = [&](int k) { return ((psx * ROWS + (k >> 1)) * TW + (k & 1) * 16) * 64; };
     auto b_off = [&](int k, int t) {
-      const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS == 9) ? t % 3 : 0;
+      const int ty = (TAPS == 9) ? t / 3 : 0, tx = (TAPS != 1) ? t % 3 : 0;
       return ((psx * ROWS + (k >> 1) + ty) * LW + (k & 1) * 16 + tx) * 64;
     };
     if constexpr (TAPS == 9) {
@@ -627,8 +630,8 @@ static bool w2_enabled() {
 
 template <int TAPS, int CB, int IB, int TH, bool RAGGED, bool D3 = false, bool RSH = false>
 static void launch_w2r(Wgrad2Params& p, int nco, int nci, hipStream_t s) {
-  constexpr int halo = TAPS == 9 ? 1 : 0;
-  constexpr int stage = IB * (TH + 2 * halo) * (32 + 2 * halo) * 64 + CB * TH * 32 * 64;
+  constexpr int halo = TAPS != 1 ? 1 : 0, halo_y = TAPS == 9 ? 1 : 0;
+  constexpr int stage = IB * (TH + 2 * halo_y) * (32 + 2 * halo) * 64 + CB * TH * 32 * 64;
   constexpr int lds = 2 * stage + 2 * 32 * IB * (int)sizeof(float);
   static bool attr = false;
   if (!attr) {
@@ -696,15 +699,19 @@ int oct_conv_wgrad_v2(const OctWgradDesc* d, const OctWgradArgs* a, void* stream
   hipStream_t s = as_stream(stream);
   p.ty0 = 0; p.pad_y = 1; p.nstore = 9;
   if (d->kh == 7) {
-    // three launches of three tap rows each (rows 0-2, 3-5, 6 + two rows beyond the kernel whose accumulators are dropped:
-    // 27 taps of MFMA work for 21); the bias gradient rides on the first
+    // three launches: tap rows 0-2 and 3-5 on the nine-tap kernel, row 6 on its one-row (three-tap) form (the first version ran
+    // row 6 on the nine-tap kernel too and dropped two rows of accumulators: 27 taps of MFMA work for 21); the bias gradient
+    // rides on the first
     const bool whole = (p.w % 32) == 0 && (p.h % 8) == 0;
     float* const dwp0 = p.dwp;
     for (int ty0 = 0; ty0 < 7; ty0 += 3) {
       p.ty0 = ty0; p.pad_y = 3; p.nstore = ty0 == 6 ? 3 : 9;
       p.dwp = dwp0 + (size_t)ty0 * 3 * d->cout * ktot;
       if (ty0 > 0) p.dbias = nullptr;
-      if (whole) launch_w2r<9, 2, 2, 8, false, false, true>(p, nco, nci, s);
+      if (ty0 == 6) {
+        if (whole) launch_w2r<3, 2, 2, 8, false, false, true>(p, nco, nci, s);
+        else launch_w2r<3, 2, 2, 8, true, false, true>(p, nco, nci, s);
+      } else if (whole) launch_w2r<9, 2, 2, 8, false, false, true>(p, nco, nci, s);
       else launch_w2r<9, 2, 2, 8, true, false, true>(p, nco, nci, s);
       if (query) break;
     }
