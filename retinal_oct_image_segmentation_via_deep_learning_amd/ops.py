@@ -90,6 +90,65 @@ def prepack(dtype: str, module: torch.nn.Module) -> None:
 
 NBT_PENDING = []   # BatchNorm step counters of the ops run since the last flush
 
+# --------------------------------------------------------------------------------------------------------------------
+# Pixel-pair folding of 16-channel 3x3 convolutions (round 3; MGU-Net with feature_scale 4: 16-channel full-resolution levels).
+# The pipelined kernels want channel counts in multiples of 32.  An NHWC tensor (n, h, w, 16k) IS the tensor (n, h, w/2, 32k) --
+# the same bytes: two horizontally adjacent pixels' channels side by side -- and a 3x3 convolution of the one is a 3x3 convolution
+# of the other with the folded filter
+#     W'[(q, co), (p, c), ty, d + 1] = W[co, c, ty, tx]   where tx = 2d + p - q + 1 in {0, 1, 2}   (zero otherwise),
+# q / p = parity of the output / input column, d in {-1, 0, 1} the folded column offset: output column 2x' + q reads input column
+# 2x' + q + tx - 1 = 2(x' + d) + p.  Half of W' is zero -- twice the FLOPs, on layers that are HBM-bound: the generic kernels ran the
+# eight 16-channel convolutions and four weight gradients of MGU-Net's first level in 7.6 of its 18.8 ms per step.  Only host code:
+# views of the activations, the folded filter (a gather), the two parities of the BatchNorm partial sums added, the filter gradient
+# un-folded (an index_add).  OCT_FOLD16=0 switches it off.
+# --------------------------------------------------------------------------------------------------------------------
+FOLD16 = [os.environ.get("OCT_FOLD16", "1") != "0"]
+_FOLD_TX = {}
+
+
+def _fold_tx(dev):
+    t = _FOLD_TX.get(dev)
+    if t is None:
+        idx = [[[(2 * d + p - q + 1) if 0 <= 2 * d + p - q + 1 <= 2 else 3 for d in (-1, 0, 1)] for p in (0, 1)] for q in (0, 1)]
+        t = _FOLD_TX[dev] = torch.tensor(idx, dtype=torch.long, device=dev)      # [q][p][d + 1] -> tx (3 = the zero column)
+    return t
+
+
+def fold16_ok(e, taps, kk, wd, c0, c1, cout) -> bool:
+    return (FOLD16[0] and e.dt == L.DT_BF16 and taps == 9 and kk is None and wd % 2 == 0 and wd >= 4 and c0 % 16 == 0 and c1 % 16 == 0
+            and cout % 16 == 0 and bool(c0 % 32 or c1 % 32 or cout % 32))
+
+
+def fold16_weight(w, c0, c1):
+    """(cout, c0 + c1, 3, 3) -> (2 cout, 2 c0 + 2 c1, 3, 3); folded input channels: [source 0: (p, c)] [source 1: (p, c)]"""
+    cout = w.shape[0]
+    g = torch.nn.functional.pad(w.detach(), (0, 1))[:, :, :, _fold_tx(w.device)]     # (cout, cin, ty, q, p, d)
+    parts = []
+    for lo, c in ((0, c0), (c0, c1)):
+        if c:
+            parts.append(g[:, lo:lo + c].permute(3, 0, 4, 1, 2, 5).reshape(2 * cout, 2 * c, 3, 3))
+    return torch.cat(parts, dim=1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+
+
+def unfold16_wgrad(dwf, cout, c0, c1):
+    """gradient of the folded filter (2 cout, 2 c0 + 2 c1, 3, 3) -> gradient of the filter (cout, c0 + c1, 3, 3)"""
+    tx = _fold_tx(dwf.device).reshape(-1)
+    parts, lo = [], 0
+    for c in (c0, c1):
+        if c:
+            g = dwf[:, lo:lo + 2 * c].reshape(2, cout, 2, c, 3, 3).permute(1, 3, 4, 0, 2, 5).reshape(cout, c, 3, 12)   # (co, c, ty, (q, p, d))
+            parts.append(torch.zeros((cout, c, 3, 4), dtype=dwf.dtype, device=dwf.device).index_add_(3, tx, g)[..., :3])
+            lo += 2 * c
+    return torch.cat(parts, dim=1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+
+
+def _fold_src(x0, c0, xf0, x1, c1, xf1):
+    n, h, wd, _ = x0.shape
+
+    def bn2(xf):
+        return BNState(xf[0].repeat(2), xf[1].repeat(2), relu=xf[2]) if xf else None
+    return Src(x0.view(n, h, wd // 2, 2 * c0), 2 * c0, bn2(xf0), None if x1 is None else x1.view(n, h, wd // 2, 2 * c1), 2 * c1, bn2(xf1))
+
 
 def flush_counters() -> None:
     """num_batches_tracked += 1 for every train-mode BatchNorm op since the last call: ONE multi-tensor launch at the end of
@@ -216,7 +275,13 @@ class ConvAffineAct(torch.autograd.Function):
         # (F_int = 8) keeps the kernel it has in BOTH activation schedules, whose results are compared bit for bit
         rowdot = (taps == 1 and x1 is None and xf0 is None and lib.oct_rowdot_ok(c0, cout) == 1 and not e.rowdot_off
                   and (cout <= 4 or bn is None))
-        wp = None if rowdot else packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
+        fold = fold16_ok(e, taps, kk, wd, c0, c1, cout)     # 16-channel 3x3: run as the pixel-pair-folded 32-channel convolution
+        if fold:
+            wf = fold16_weight(w, c0, c1)
+            wp = packed(e, wf, L.PACK_CONV_FPROP, 2 * cout, 2 * cin, cache=False)
+            srcf = _fold_src(x0, c0, xf0, x1, c1, xf1)
+        else:
+            wp = None if rowdot else packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
         y = e._act(n, h, wd, cout, dev)
         scale = torch.empty(cout, dtype=torch.float32, device=dev)
         shift = torch.empty_like(scale)
@@ -227,6 +292,8 @@ class ConvAffineAct(torch.autograd.Function):
             if rowdot:
                 L.check(lib.oct_rowdot_fwd(e.dt, x0.data_ptr(), w.data_ptr(), y.data_ptr(), L.ptr(stats), n * h * wd, c0, cout,
                                            _stream()), "oct_rowdot_fwd")
+            elif fold:
+                e._conv(srcf, wp, 2 * cout, 9, n, h, wd // 2, y.view(n, h, wd // 2, 2 * cout), stats=stats)
             else:
                 e._conv(src, wp, cout, taps, n, h, wd, y, stats=stats, **kd)
 
@@ -234,9 +301,15 @@ class ConvAffineAct(torch.autograd.Function):
             # torch's batch_norm refuses a single value per channel in training mode (functional.py, _verify_batch_size)
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {torch.Size([n, cout, h, wd])}")
         if train_bn:
-            nblk = lib.oct_rowdot_blocks(n * h * wd, c0) if rowdot else e._stat_blocks(cout, n, h, wd, src, taps, **kd)
-            partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
-            conv(partials)
+            if fold:
+                nblk = e._stat_blocks(2 * cout, n, h, wd // 2, srcf, 9)
+                pf = torch.empty((nblk, 2, 2 * cout), dtype=torch.float32, device=dev)
+                conv(pf)
+                partials = pf.view(nblk, 2, 2, cout).sum(2)     # the two column parities of a channel
+            else:
+                nblk = lib.oct_rowdot_blocks(n * h * wd, c0) if rowdot else e._stat_blocks(cout, n, h, wd, src, taps, **kd)
+                partials = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev)
+                conv(partials)
             mean, invstd = torch.empty_like(scale), torch.empty_like(scale)
             L.check(lib.oct_bn_finalize(partials.data_ptr(), nblk, cout, float(n * h * wd), gamma.data_ptr(),
                                         beta.data_ptr(), BN_EPS, BN_MOMENTUM, bn.running_mean.data_ptr(),
@@ -260,6 +333,7 @@ class ConvAffineAct(torch.autograd.Function):
         ctx.cfg = (dtype, bn, act, taps, train_bn, res is not None, cbias is not None, kk, lazy)
         ctx.xf = (xf0, xf1)
         ctx.rowdot = rowdot
+        ctx.fold = fold
         if lazy == "relu":
             ctx.save_for_backward(x0, x1, w, y, None, mean, invstd, scale, gamma, shift, alpha)
             ctx.mark_non_differentiable(scale, shift)
@@ -363,7 +437,7 @@ class ConvAffineAct(torch.autograd.Function):
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev) if train_bn else coef[0] * partials[:, 0, :].sum(0)
         else:
             dy = dz
-            if has_bias and cin % 32 == 0 and not ctx.rowdot:
+            if has_bias and cin % 32 == 0 and not ctx.rowdot and not ctx.fold:
                 # bias gradient = sum over pixels of dY: one extra MFMA against a ones fragment inside the weight-gradient
                 # kernel instead of a separate pass over dY (the direct first-layer kernel has no such path: cin = 1, 3 ...)
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
@@ -396,6 +470,21 @@ class ConvAffineAct(torch.autograd.Function):
                                mean=None if mean is None else mean.clone(), invstd=None if invstd is None else invstd.clone(),
                                scale=scale.clone(), shift=shift.clone(),
                                dbeta=None if dbeta is None else dbeta.clone())))
+        if ctx.fold:    # the pixel-pair-folded convolution (see fold16_ok): same tensors viewed (n, h, w/2, 2c), folded filter
+            srcf = _fold_src(x0, c0, xf0, x1, c1, xf1)
+            dyf = dy.view(n, h, wd // 2, 2 * cout)
+            dwpf = e._wgrad(srcf, dyf, 2 * cout, 9, n, h, wd // 2)
+            dwf = torch.empty((2 * cout, 2 * cin, 3, 3), dtype=w.dtype, device=dev)
+            e._unpack(L.PACK_CONV_FPROP, dwpf, dwf, 2 * cout, 2 * cin, False)
+            dw = unfold16_wgrad(dwf, cout, c0, c1)
+            d0 = d1 = None
+            if ctx.needs_input_grad[3] or (x1 is not None and ctx.needs_input_grad[4]):
+                wpd = packed(e, fold16_weight(w, c0, c1), L.PACK_CONV_DGRAD, 2 * cout, 2 * cin, cache=False)
+                d0 = e._act(n, h, wd, c0, dev)
+                d1 = e._act(n, h, wd, c1, dev) if c1 else None
+                e._conv(Src(dyf, 2 * cout), wpd, 2 * cin, 9, n, h, wd // 2, d0.view(n, h, wd // 2, 2 * c0),
+                        y1=None if d1 is None else d1.view(n, h, wd // 2, 2 * c1), split=2 * c0 if c1 else 0)
+            return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres, dalpha, None, None, None, None
         src = Src(x0, c0, BNState(xf0[0], xf0[1], relu=xf0[2]) if xf0 else None,
                   x1, c1, BNState(xf1[0], xf1[1], relu=xf1[2]) if xf1 else None)
         dwp = e._wgrad(src, dy, cout, taps, n, h, wd, dbias=dcb if fuse_bias else None, partials_ok=not kk, **kd)

@@ -178,3 +178,50 @@ def test_floor_mode_maxpool_matches_torch(dtype, k, h, w):
     ref.backward(r.float().permute(0, 3, 1, 2))
     assert torch.equal(out.float().cpu(), ref.detach().permute(0, 2, 3, 1))
     assert torch.equal(xd.grad.float().cpu(), xr.grad.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 64, 16, 0, 16), (1, 9, 40, 16, 16, 16), (1, 16, 96, 16, 0, 32), (2, 8, 32, 48, 16, 16),
+                                   (1, 6, 8, 32, 0, 16)])
+def test_sixteen_channel_conv3x3_runs_pixel_pair_folded_and_is_bit_exact(shape):
+    """MGU-Net's 16-channel levels (MGUNet_2021.py:118-126 with feature_scale 4): a 3x3 convolution whose channel counts are
+    multiples of 16 but not all of 32 runs as the pixel-pair-FOLDED convolution on the pipelined kernels (ops.fold16_ok) --
+    output, BatchNorm statistics, input gradients (concat split) and the un-folded weight gradient against torch's float64
+    convolution on exactly representable operands: bit equality (odd and even tile counts, ragged widths, concat sources)."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops, _lib as L
+    n, h, w, c0, c1, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    e = ops.kernels("bf16")
+    assert ops.fold16_ok(e, 9, None, w, c0, c1, cout) and not ops.fold16_ok(e, 9, None, w + 1, c0, c1, cout)
+    cin = c0 + c1
+    x = torch.randint(-3, 4, (n, cin, h, w), generator=g).double()
+    wt = (torch.exp2(torch.randint(-3, 1, (cout, cin, 3, 3), generator=g).double()) * (torch.randint(0, 2, (cout, cin, 3, 3), generator=g) * 2 - 1)
+          * (torch.rand((cout, cin, 3, 3), generator=g) < 0.4))
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(wt.float())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    a0 = nhwc(x[:, :c0]).requires_grad_(True)
+    a1 = nhwc(x[:, c0:]).requires_grad_(True) if c1 else None
+    bn = torch.nn.BatchNorm2d(cout).cuda().train()
+    y, scale, shift = ops.ConvAffineAct.apply("bf16", bn, L.ACT_RELU, a0, a1, conv.weight, None, bn.weight, bn.bias, None, None, None,
+                                              None, "relu")       # the raw conv output of a deferred BN + ReLU layer
+    ref = F.conv2d(x, wt, padding=1)
+    rnd = lambda t: t.float().to(torch.bfloat16).double()
+    assert torch.equal(y.detach().float().cpu().double().permute(0, 3, 1, 2), rnd(ref)), "folded forward"
+    mean = ref.mean(dim=(0, 2, 3))
+    torch.testing.assert_close(bn.running_mean.double().cpu(), 0.1 * mean, rtol=1e-5, atol=1e-6)
+    # backward of the raw output alone: a second, bare (no BatchNorm) application gives dx / dW without the BN terms
+    a0b = nhwc(x[:, :c0]).requires_grad_(True)
+    a1b = nhwc(x[:, c0:]).requires_grad_(True) if c1 else None
+    yb = ops.conv_bn_act("bf16", a0b, conv, x1=a1b)
+    assert torch.equal(yb.detach().float().cpu().double().permute(0, 3, 1, 2), rnd(ref))
+    dy = torch.randint(-2, 3, (n, cout, h, w), generator=g).double() * (torch.rand((n, cout, h, w), generator=g) < 0.5)
+    conv.weight.grad = None
+    yb.backward(nhwc(dy))
+    dx = torch.nn.grad.conv2d_input((n, cin, h, w), wt, dy, padding=1)
+    dw = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, padding=1)
+    assert torch.equal(a0b.grad.float().cpu().double().permute(0, 3, 1, 2), rnd(dx[:, :c0])), "folded dgrad, source 0"
+    if c1:
+        assert torch.equal(a1b.grad.float().cpu().double().permute(0, 3, 1, 2), rnd(dx[:, c0:])), "folded dgrad, source 1"
+    assert dw.abs().max() * 2 < 2 ** 23
+    assert torch.equal(conv.weight.grad.double().cpu(), dw), "un-folded weight gradient"
