@@ -115,15 +115,24 @@ def _fold_tx(dev):
 
 
 def fold16_ok(e, taps, kk, wd, c0, c1, cout) -> bool:
-    return (FOLD16[0] and e.dt == L.DT_BF16 and taps == 9 and kk is None and wd % 2 == 0 and wd >= 4 and c0 % 16 == 0 and c1 % 16 == 0
+    return (FOLD16[0] and e.dt == L.DT_BF16 and taps in (1, 9) and kk is None and wd % 2 == 0 and wd >= 4 and c0 % 16 == 0 and c1 % 16 == 0
             and cout % 16 == 0 and bool(c0 % 32 or c1 % 32 or cout % 32))
 
 
 def fold16_weight(w, c0, c1):
     """(cout, c0 + c1, 3, 3) -> (2 cout, 2 c0 + 2 c1, 3, 3); folded input channels: [source 0: (p, c)] [source 1: (p, c)]"""
     cout = w.shape[0]
-    g = torch.nn.functional.pad(w.detach(), (0, 1))[:, :, :, _fold_tx(w.device)]     # (cout, cin, ty, q, p, d)
     parts = []
+    if w.shape[2] == 1:     # 1x1: the two column parities do not mix -- [[W, 0], [0, W]] per source
+        wd_ = w.detach()
+        for lo, c in ((0, c0), (c0, c1)):
+            if c:
+                t = torch.zeros((2, cout, 2, c, 1, 1), dtype=w.dtype, device=w.device)
+                t[0, :, 0] = wd_[:, lo:lo + c]
+                t[1, :, 1] = wd_[:, lo:lo + c]
+                parts.append(t.reshape(2 * cout, 2 * c, 1, 1))
+        return torch.cat(parts, dim=1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+    g = torch.nn.functional.pad(w.detach(), (0, 1))[:, :, :, _fold_tx(w.device)]     # (cout, cin, ty, q, p, d)
     for lo, c in ((0, c0), (c0, c1)):
         if c:
             parts.append(g[:, lo:lo + c].permute(3, 0, 4, 1, 2, 5).reshape(2 * cout, 2 * c, 3, 3))
@@ -132,8 +141,15 @@ def fold16_weight(w, c0, c1):
 
 def unfold16_wgrad(dwf, cout, c0, c1):
     """gradient of the folded filter (2 cout, 2 c0 + 2 c1, 3, 3) -> gradient of the filter (cout, c0 + c1, 3, 3)"""
-    tx = _fold_tx(dwf.device).reshape(-1)
     parts, lo = [], 0
+    if dwf.shape[2] == 1:
+        for c in (c0, c1):
+            if c:
+                t = dwf[:, lo:lo + 2 * c].reshape(2, cout, 2, c, 1, 1)
+                parts.append(t[0, :, 0] + t[1, :, 1])
+                lo += 2 * c
+        return torch.cat(parts, dim=1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+    tx = _fold_tx(dwf.device).reshape(-1)
     for c in (c0, c1):
         if c:
             g = dwf[:, lo:lo + 2 * c].reshape(2, cout, 2, c, 3, 3).permute(1, 3, 4, 0, 2, 5).reshape(cout, c, 3, 12)   # (co, c, ty, (q, p, d))
@@ -278,7 +294,7 @@ class ConvAffineAct(torch.autograd.Function):
         fold = fold16_ok(e, taps, kk, wd, c0, c1, cout)     # 16-channel 3x3: run as the pixel-pair-folded 32-channel convolution
         if fold:
             wf = fold16_weight(w, c0, c1)
-            wp = packed(e, wf, L.PACK_CONV_FPROP, 2 * cout, 2 * cin, cache=False)
+            wp = packed(e, wf, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, 2 * cout, 2 * cin, cache=False)
             srcf = _fold_src(x0, c0, xf0, x1, c1, xf1)
         else:
             wp = None if rowdot else packed(e, w, L.PACK_1X1_FPROP if taps == 1 else L.PACK_CONV_FPROP, cout, cin, kk=kk)
@@ -293,7 +309,7 @@ class ConvAffineAct(torch.autograd.Function):
                 L.check(lib.oct_rowdot_fwd(e.dt, x0.data_ptr(), w.data_ptr(), y.data_ptr(), L.ptr(stats), n * h * wd, c0, cout,
                                            _stream()), "oct_rowdot_fwd")
             elif fold:
-                e._conv(srcf, wp, 2 * cout, 9, n, h, wd // 2, y.view(n, h, wd // 2, 2 * cout), stats=stats)
+                e._conv(srcf, wp, 2 * cout, taps, n, h, wd // 2, y.view(n, h, wd // 2, 2 * cout), stats=stats)
             else:
                 e._conv(src, wp, cout, taps, n, h, wd, y, stats=stats, **kd)
 
@@ -302,7 +318,7 @@ class ConvAffineAct(torch.autograd.Function):
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {torch.Size([n, cout, h, wd])}")
         if train_bn:
             if fold:
-                nblk = e._stat_blocks(2 * cout, n, h, wd // 2, srcf, 9)
+                nblk = e._stat_blocks(2 * cout, n, h, wd // 2, srcf, taps)
                 pf = torch.empty((nblk, 2, 2 * cout), dtype=torch.float32, device=dev)
                 conv(pf)
                 partials = pf.view(nblk, 2, 2, cout).sum(2)     # the two column parities of a channel
@@ -473,16 +489,16 @@ class ConvAffineAct(torch.autograd.Function):
         if ctx.fold:    # the pixel-pair-folded convolution (see fold16_ok): same tensors viewed (n, h, w/2, 2c), folded filter
             srcf = _fold_src(x0, c0, xf0, x1, c1, xf1)
             dyf = dy.view(n, h, wd // 2, 2 * cout)
-            dwpf = e._wgrad(srcf, dyf, 2 * cout, 9, n, h, wd // 2)
-            dwf = torch.empty((2 * cout, 2 * cin, 3, 3), dtype=w.dtype, device=dev)
-            e._unpack(L.PACK_CONV_FPROP, dwpf, dwf, 2 * cout, 2 * cin, False)
+            dwpf = e._wgrad(srcf, dyf, 2 * cout, taps, n, h, wd // 2)
+            dwf = torch.empty((2 * cout, 2 * cin) + tuple(w.shape[2:]), dtype=w.dtype, device=dev)
+            e._unpack(L.PACK_CONV_FPROP if taps == 9 else L.PACK_1X1_FPROP, dwpf, dwf, 2 * cout, 2 * cin, False)
             dw = unfold16_wgrad(dwf, cout, c0, c1)
             d0 = d1 = None
             if ctx.needs_input_grad[3] or (x1 is not None and ctx.needs_input_grad[4]):
-                wpd = packed(e, fold16_weight(w, c0, c1), L.PACK_CONV_DGRAD, 2 * cout, 2 * cin, cache=False)
+                wpd = packed(e, fold16_weight(w, c0, c1), L.PACK_CONV_DGRAD if taps == 9 else L.PACK_1X1_DGRAD, 2 * cout, 2 * cin, cache=False)
                 d0 = e._act(n, h, wd, c0, dev)
                 d1 = e._act(n, h, wd, c1, dev) if c1 else None
-                e._conv(Src(dyf, 2 * cout), wpd, 2 * cin, 9, n, h, wd // 2, d0.view(n, h, wd // 2, 2 * c0),
+                e._conv(Src(dyf, 2 * cout), wpd, 2 * cin, taps, n, h, wd // 2, d0.view(n, h, wd // 2, 2 * c0),
                         y1=None if d1 is None else d1.view(n, h, wd // 2, 2 * c1), split=2 * c0 if c1 else 0)
             return None, None, None, d0, d1, dw, dcb, dgamma, dbeta, dres, dalpha, None, None, None, None
         src = Src(x0, c0, BNState(xf0[0], xf0[1], relu=xf0[2]) if xf0 else None,

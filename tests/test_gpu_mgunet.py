@@ -225,3 +225,34 @@ def test_sixteen_channel_conv3x3_runs_pixel_pair_folded_and_is_bit_exact(shape):
         assert torch.equal(a1b.grad.float().cpu().double().permute(0, 3, 1, 2), rnd(dx[:, c0:])), "folded dgrad, source 1"
     assert dw.abs().max() * 2 < 2 ** 23
     assert torch.equal(conv.weight.grad.double().cpu(), dw), "un-folded weight gradient"
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 64, 16, 0, 16), (1, 9, 40, 16, 16, 32), (1, 5, 8, 48, 0, 16)])
+def test_sixteen_channel_conv1x1_runs_pixel_pair_folded_and_is_bit_exact(shape):
+    """the same for 1x1 convolutions (the folded filter is [[W, 0], [0, W]]: the two column parities do not mix)"""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    n, h, w, c0, c1, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    e = ops.kernels("bf16")
+    assert ops.fold16_ok(e, 1, None, w, c0, c1, cout)
+    cin = c0 + c1
+    x = torch.randint(-3, 4, (n, cin, h, w), generator=g).double()
+    wt = torch.exp2(torch.randint(-3, 1, (cout, cin, 1, 1), generator=g).double()) * (torch.randint(0, 2, (cout, cin, 1, 1), generator=g) * 2 - 1)
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(wt.float())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    a0 = nhwc(x[:, :c0]).requires_grad_(True)
+    a1 = nhwc(x[:, c0:]).requires_grad_(True) if c1 else None
+    y = ops.conv_bn_act("bf16", a0, conv, x1=a1)
+    ref = F.conv2d(x, wt)
+    rnd = lambda t: t.float().to(torch.bfloat16).double()
+    assert torch.equal(y.detach().float().cpu().double().permute(0, 3, 1, 2), rnd(ref)), "folded 1x1 forward"
+    dy = torch.randint(-2, 3, (n, cout, h, w), generator=g).double()
+    y.backward(nhwc(dy))
+    dx = torch.nn.grad.conv2d_input((n, cin, h, w), wt, dy)
+    dw = torch.nn.grad.conv2d_weight(x, (cout, cin, 1, 1), dy)
+    assert torch.equal(a0.grad.float().cpu().double().permute(0, 3, 1, 2), rnd(dx[:, :c0]))
+    if c1:
+        assert torch.equal(a1.grad.float().cpu().double().permute(0, 3, 1, 2), rnd(dx[:, c0:]))
+    assert torch.equal(conv.weight.grad.double().cpu(), dw), "un-folded 1x1 weight gradient"
