@@ -158,6 +158,27 @@ def unfold16_wgrad(dwf, cout, c0, c1):
     return torch.cat(parts, dim=1).contiguous() if len(parts) > 1 else parts[0].contiguous()
 
 
+def fold16_deconv_weight(w):
+    """ConvTranspose2d(k = 2, s = 2) weight (cin, cout, 2, 2) -> folded (2 cin, 2 cout, 2, 2): input pixel pair (pi, c), output channels
+    (dx, co), kernel (dy, pi): out[2y + dy, 2x'' + pi, (dx, co)] = sum_c x[y, x'', (pi, c)] W[c, co, dy, dx] -- the two input parities do
+    not mix, the horizontal kernel offset becomes the channel half"""
+    cin, cout = w.shape[0], w.shape[1]
+    t = torch.zeros((2, cin, 2, cout, 2, 2), dtype=w.dtype, device=w.device)     # (pi', c, dx, co, dy, pi)
+    wp_ = w.detach().permute(0, 3, 1, 2)                                           # (c, dx, co, dy)
+    t[0, :, :, :, :, 0] = wp_
+    t[1, :, :, :, :, 1] = wp_
+    return t.reshape(2 * cin, 2 * cout, 2, 2)
+
+
+def unfold16_deconv_wgrad(dwf, cin, cout):
+    t = dwf.reshape(2, cin, 2, cout, 2, 2)
+    return (t[0, :, :, :, :, 0] + t[1, :, :, :, :, 1]).permute(0, 2, 3, 1).contiguous()   # (c, dx, co, dy) -> (c, co, dy, dx)
+
+
+def fold16_deconv_ok(e, k, wd, cin, cout) -> bool:
+    return (FOLD16[0] and e.dt == L.DT_BF16 and k == 2 and wd % 2 == 0 and cin % 16 == 0 and cout % 16 == 0 and bool(cin % 32 or cout % 32))
+
+
 def _fold_src(x0, c0, xf0, x1, c1, xf1):
     n, h, wd, _ = x0.shape
 
@@ -738,7 +759,13 @@ class Deconv(torch.autograd.Function):
             raise RuntimeError(f"transposed-conv weight {tuple(w.shape)} does not fit {cin} input channels / k in (2, 4)")
         cout, k = w.shape[1], w.shape[2]
         out = e._act(n, h * k, wd * k, cout, x.device)
-        if k == 2:
+        fold = fold16_deconv_ok(e, k, wd, cin, cout)
+        if fold:    # 16-channel transposed convolution, pixel-pair folded (see fold16_ok): 2 cin -> 2 cout on (n, h, w/2)
+            wp = packed(e, fold16_deconv_weight(w), L.PACK_DECONV_FPROP, 2 * cout, 2 * cin, cache=False)
+            e._conv(Src(x.view(n, h, wd // 2, 2 * cin), 2 * cin), wp, 8 * cout, 1, n, h, wd // 2, out.view(n, 2 * h, wd, 2 * cout),
+                    out_mode=L.OUT_D2S, bias=bias.detach().repeat(2).contiguous())
+            w1 = None
+        elif k == 2:
             wp = packed(e, w, L.PACK_DECONV_FPROP, cout, cin)
             e._conv(Src(x, cin), wp, 4 * cout, 1, n, h, wd, out, out_mode=L.OUT_D2S, bias=bias)
             w1 = None
@@ -750,6 +777,7 @@ class Deconv(torch.autograd.Function):
             L.check(L.lib().oct_depth_to_space(e.dt, y.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, wd, cout, k,
                                                _stream()), "oct_depth_to_space")
         ctx.cfg = (dtype, k)
+        ctx.fold = fold
         ctx.save_for_backward(x, w, w1)
         return out
 
@@ -766,7 +794,20 @@ class Deconv(torch.autograd.Function):
         dw = torch.empty_like(w)
         db = torch.zeros(cout, dtype=torch.float32, device=dev)
         dx = None
-        if k == 2:
+        if ctx.fold:
+            xf = x.view(n, h, wd // 2, 2 * cin)
+            df = dout.view(n, 2 * h, wd, 2 * cout)
+            db2 = torch.zeros(2 * cout, dtype=torch.float32, device=dev)
+            dwp = e._wgrad(Src(xf, 2 * cin), df, 8 * cout, 1, n, h, wd // 2, dy_mode=L.IN_S2D, dbias=db2)
+            dwf = torch.empty((2 * cin, 2 * cout, 2, 2), dtype=w.dtype, device=dev)
+            e._unpack(L.PACK_DECONV_FPROP, dwp, dwf, 2 * cout, 2 * cin, False)
+            dw = unfold16_deconv_wgrad(dwf, cin, cout)
+            db = db2.view(2, cout).sum(0)
+            if ctx.needs_input_grad[1]:
+                wp = packed(e, fold16_deconv_weight(w), L.PACK_DECONV_DGRAD, 2 * cout, 2 * cin, cache=False)
+                dx = e._act(n, h, wd, cin, dev)
+                e._conv(Src(df, 2 * cout), wp, 2 * cin, 1, n, h, wd // 2, dx.view(n, h, wd // 2, 2 * cin), in_mode=L.IN_S2D)
+        elif k == 2:
             dwp = e._wgrad(Src(x, cin), dout, 4 * cout, 1, n, h, wd, dy_mode=L.IN_S2D, dbias=db)
             e._unpack(L.PACK_DECONV_FPROP, dwp, dw, cout, cin, False)
             if ctx.needs_input_grad[1]:

@@ -256,3 +256,32 @@ def test_sixteen_channel_conv1x1_runs_pixel_pair_folded_and_is_bit_exact(shape):
     if c1:
         assert torch.equal(a1.grad.float().cpu().double().permute(0, 3, 1, 2), rnd(dx[:, c0:]))
     assert torch.equal(conv.weight.grad.double().cpu(), dw), "un-folded 1x1 weight gradient"
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 32, 32, 16), (1, 5, 8, 16, 16), (1, 8, 64, 48, 16), (2, 4, 12, 16, 32)])
+def test_sixteen_channel_deconv_runs_pixel_pair_folded_and_is_bit_exact(shape):
+    """ConvTranspose2d(k = 2, s = 2) with 16-channel sides (MGU-Net's UnetUp at feature_scale 4, MGUNet_2021.py:72-89) as the folded
+    transposed convolution (ops.fold16_deconv_ok): output with bias, input gradient, un-folded weight gradient and bias gradient
+    against torch's float64 conv_transpose2d on exactly representable operands."""
+    from retinal_oct_image_segmentation_via_deep_learning_amd import ops
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 3)
+    e = ops.kernels("bf16")
+    assert ops.fold16_deconv_ok(e, 2, w, cin, cout)
+    x = torch.randint(-3, 4, (n, cin, h, w), generator=g).double()
+    wt = torch.exp2(torch.randint(-3, 1, (cin, cout, 2, 2), generator=g).double()) * (torch.randint(0, 2, (cin, cout, 2, 2), generator=g) * 2 - 1)
+    b = torch.randint(-2, 3, (cout,), generator=g).double() * 0.5
+    a = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda().requires_grad_(True)
+    wd_ = wt.float().cuda().requires_grad_(True)
+    bd = b.float().cuda().requires_grad_(True)
+    out = ops.Deconv.apply("bf16", a, wd_, bd)
+    ref = F.conv_transpose2d(x, wt, b, stride=2)
+    rnd = lambda t: t.float().to(torch.bfloat16).double()
+    assert torch.equal(out.detach().float().cpu().double().permute(0, 3, 1, 2), rnd(ref)), "folded deconv forward"
+    dy = torch.randint(-2, 3, ref.shape, generator=g).double()
+    out.backward(dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda())
+    xr = x.clone().requires_grad_(True); wr = wt.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    (F.conv_transpose2d(xr, wr, br, stride=2) * dy).sum().backward()
+    assert torch.equal(a.grad.float().cpu().double().permute(0, 3, 1, 2), rnd(xr.grad)), "folded deconv dgrad"
+    assert torch.equal(wd_.grad.double().cpu(), wr.grad), "un-folded deconv weight gradient"
+    assert torch.equal(bd.grad.double().cpu(), br.grad), "deconv bias gradient"
