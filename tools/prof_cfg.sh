@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 python3 - "$O/ks_$TAG" "$STEPS" "$CFG" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]
-steps = int(sys.argv[2]) + 2 + (1 if sys.argv[3] == "cfg2" else 0)      # timed + warm-up (+ the roofline step of cfg2)
+steps = int(sys.argv[2]) + (8 if sys.argv[3] in ("relaynet", "mgunet2") else 2) + (1 if sys.argv[3] == "cfg2" else 0)      # timed + warm-up (bench.py warms the autograd configs up for 8 steps) (+ the roofline step of cfg2)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6 / steps
 print(f"{sys.argv[3]}: sum of all kernels {tot:.2f} ms/step over {steps} steps")
