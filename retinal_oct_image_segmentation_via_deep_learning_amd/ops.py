@@ -402,6 +402,7 @@ class ConvAffineAct(torch.autograd.Function):
         fuse_bias = False
         prelu_fused = False
         rowdot_bias = False
+        fold_bias = False
         e = kernels(dtype)
         lib = L.lib()
         n, h, wd, c0 = x0.shape
@@ -479,6 +480,8 @@ class ConvAffineAct(torch.autograd.Function):
                 # kernel instead of a separate pass over dY (the direct first-layer kernel has no such path: cin = 1, 3 ...)
                 dcb = torch.zeros(cout, dtype=torch.float32, device=dev)
                 fuse_bias = True
+            elif has_bias and ctx.fold:
+                fold_bias = True        # rides on the folded weight-gradient kernel (both column parities, added below)
             elif has_bias and ctx.rowdot:
                 rowdot_bias = True      # rides on the streaming weight-gradient pass below
                 dcb = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -510,7 +513,10 @@ class ConvAffineAct(torch.autograd.Function):
         if ctx.fold:    # the pixel-pair-folded convolution (see fold16_ok): same tensors viewed (n, h, w/2, 2c), folded filter
             srcf = _fold_src(x0, c0, xf0, x1, c1, xf1)
             dyf = dy.view(n, h, wd // 2, 2 * cout)
-            dwpf = e._wgrad(srcf, dyf, 2 * cout, taps, n, h, wd // 2)
+            db2 = torch.zeros(2 * cout, dtype=torch.float32, device=dev) if fold_bias else None
+            dwpf = e._wgrad(srcf, dyf, 2 * cout, taps, n, h, wd // 2, dbias=db2)
+            if fold_bias:
+                dcb = db2.view(2, cout).sum(0)
             dwf = torch.empty((2 * cout, 2 * cin) + tuple(w.shape[2:]), dtype=w.dtype, device=dev)
             e._unpack(L.PACK_CONV_FPROP if taps == 9 else L.PACK_1X1_FPROP, dwpf, dwf, 2 * cout, 2 * cin, False)
             dw = unfold16_wgrad(dwf, cout, c0, c1)
