@@ -8,7 +8,7 @@ for f in glob.glob(sys.argv[1] + "/*/*counter_collection.csv"):
                                                     "t0": int(r.get("Start_Timestamp", 0) or 0), "t1": int(r.get("End_Timestamp", 0) or 0)})
         d[r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
-conv = [i for i in ids if any(k in rows[i]["name"] for k in ("igemm2_kernel", "gemm1_kernel", "wgrad2_kernel", "first_fprop", "first_wgrad"))]
+conv = [i for i in ids if any(k in rows[i]["name"] for k in ("igemm2_kernel", "gemm1_kernel", "wgrad2_kernel", "first_fprop", "first_wgrad", "roll3d_kernel"))]
 # the last step = the conv launches after the last optimizer step but one
 sgd = [i for i in ids if "sgd" in rows[i]["name"].lower()]
 lo = sgd[-2] if len(sgd) >= 2 else 0
