@@ -1367,7 +1367,11 @@ static V2Plan plan_v2(const OctConvDesc* d) {
   // Cout = 32 (full-resolution, HBM-bound layers): 16-row tiles halve the halo overhead per output pixel
   // 16-row tiles: Cout = 32 always; Cout = 64 with streamed weights in fprop (each wave then owns 4 rows x 64
   // channels: half the LDS reads per MFMA, halo overhead 18/16) -- measured -2 % on fprop, neutral to worse on dgrad
-  pl.th = (d->taps == 9 && (pl.nt == 32 || (pl.nt == 64 && d->want_stats && !pl.wres)) && (d->h % 16) == 0) ? 16 : 8;
+#ifndef IG2_TH16_DGRAD
+#define IG2_TH16_DGRAD 1   /* 64-channel data gradients on the 16-row two-fragment tiling too (full-line stores, MRG): 0.358 -> 0.309, 0.334 -> 0.297, 0.155 -> 0.144 ms on the three launches of cfg2 (same box) */
+#endif
+  // (the two-fragment tilings store a wave's 64 channels as one line: a concat split inside them -- split % 64 != 0 -- keeps the one-fragment tiling)
+  pl.th = (d->taps == 9 && (pl.nt == 32 || (pl.nt == 64 && (d->want_stats || IG2_TH16_DGRAD) && !pl.wres && (d->split % 64) == 0)) && (d->h % 16) == 0) ? 16 : 8;
   const int ntiles = ((d->w + 31) / 32) * ((d->h + pl.th - 1) / pl.th) * d->n;
   pl.nitems = ntiles * pl.nblk;
   int target = 256;  // one persistent workgroup per CU (only one fits the LDS); 512 measured 2 % slower on dgrad, 1024 4 %
